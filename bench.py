@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the rag-fin vector-retrieval hot path on MI355X.
+
+Metric (BASELINE.json): queries/sec, top-10, 1M x 384-d fp16 corpus, batch=64,
+with recall@10 vs the CPU oracle.  A "step" is one pass of the hot path over one
+batch: 64 query embeddings (already in HBM) -> brute-force cosine/IP top-10 over
+the HBM-resident corpus -> ranked (score, row id) lists in HBM.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: the corpus is row-sharded (1M rows per GPU, weak scaling), the query batch
+is replicated, and each step ends with ONE RCCL all-gather of the per-shard top-k
+plus a merge (rag_fin_amd/sharded.py).  `value` stays "queries/sec of the whole
+job" -- the job answers the same 64 queries per step against an N-times larger
+corpus -- so under weak scaling the ideal is a flat value; `rows_per_s` in the
+JSON carries the aggregate scan rate that grows with N.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="corpus rows PER GPU")
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def pmc_traffic(rows, dim):
+    """HBM bytes per emit-scan launch from the committed PMC passes, if they were
+    taken on this workload (profiles/*_pmc.json; see DESIGN.md 'Measurement')."""
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+            rec = json.load(open(path))
+            if rec.get("rows") == rows and rec.get("dim") == dim:
+                return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run "
+                             "(one process per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from oracle import search as osearch
+    from rag_fin_amd.sharded import HipShardBackend, ShardedSearcher
+    from rag_fin_amd.store import GpuIndex
+
+    rows, dim, B, k = args.rows, args.dim, args.batch, args.topk
+    # synthetic data, SURVEY.md 8d recipe: N(0,1) rows, L2-normalised, fp16
+    c16 = osearch.synth_unit_rows(rows, dim, 1234 + rank)
+    q16 = osearch.synth_unit_rows(B, dim, 5678)
+    index = GpuIndex(dim, rows, dev)
+    step_rows = 1 << 18
+    for s in range(0, rows, step_rows):
+        index.add(torch.from_numpy(c16[s:s + step_rows]).to(dev))
+    q = torch.from_numpy(q16).to(dev)
+    torch.cuda.synchronize()
+
+    searcher = ShardedSearcher(HipShardBackend(index), row_base=rank * rows) if world > 1 else None
+    out = (torch.empty((B, k), dtype=torch.float32, device=dev),
+           torch.empty((B, k), dtype=torch.int64, device=dev),
+           torch.empty((B, k), dtype=torch.float64, device=dev),
+           torch.empty((B,), dtype=torch.int32, device=dev))
+
+    def step():
+        if searcher is None:
+            return index.search_raw(q, k, want_exact=True, out=out)
+        return searcher.search(q, k)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        res = step()
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # flags must be clean for the number to count as an exact search
+    flags = res[3] if searcher is None else res[2]
+    flags_clean = int(flags.abs().sum().item()) == 0
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        qps = B * args.steps / elapsed
+        # dominant kernel (emit scan) timed with HIP events, stage by stage
+        stages = [index.search_profile(q, k) for _ in range(max(10, min(50, args.steps)))]
+        emit_ms = float(np.mean([s["emit"] for s in stages]))
+        stage_avg = {n: float(np.mean([s[n] for s in stages])) for n in stages[0]}
+        alg_bytes = rows * dim * 2  # corpus read once per batch
+        achieved = alg_bytes / (emit_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(rows, dim)
+        result = {
+            "metric": "queries/sec, brute-force cosine/IP top-%d over a %s x %d-d fp16 corpus, "
+                      "batch=%d (recall@10 vs CPU oracle reported alongside)" % (k, f"{rows:,}", dim, B),
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "1M x 384-d fp16 corpus, batch-64 queries, top-10"
+                       if (rows, dim, B, k) == (1_000_000, 384, 64, 10)
+                       else f"{rows} x {dim}-d fp16 corpus per GPU, batch-{B}, top-{k}",
+                       "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "batch": B,
+                       "topk": k, "sharding": "none" if world == 1 else f"rows/{world} + RCCL all-gather"},
+            "rows_per_s": round(rows * world * args.steps / elapsed, 1),
+            "hip_event_ms_per_step": round(ev_ms / args.steps, 5),
+            "whole_step_GBps": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            "stage_ms": {n: round(v, 5) for n, v in stage_avg.items()},
+            "flags_clean": flags_clean,
+            "roofline": {"bound": "hbm", "kernel": "k_scan<MODE_EMIT>", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+
+        # ---- correctness beside the number: recall@10 / exact ids vs the CPU oracle
+        if not args.no_check:
+            from oracle import c_oracle
+            nq = min(8, B)
+            if searcher is None:
+                gi = out[1][:nq].cpu().numpy()
+                ge = out[2][:nq].cpu().numpy()
+            else:
+                s_, i_, e_, f_ = index.search_raw(q[:nq], k, want_exact=True)
+                gi, ge = i_.cpu().numpy(), e_.cpu().numpy()
+            os_, oi = c_oracle.search(q16[:nq], c16, k)
+            recall = float(np.mean([len(set(gi[b]) & set(oi[b])) / k for b in range(nq)]))
+            result["recall_at_10"] = recall
+            result["ids_ranks_exact"] = bool(np.array_equal(gi, oi))
+            result["max_abs_score_err"] = float(np.abs(ge - os_).max())
+            result["checked_queries"] = nq
+
+        # ---- CPU baseline leg (rank 0, N=1 only): the oracle's BLAS restatement of the
+        # reference's search semantics on the host cores, same data
+        if world == 1 and not args.no_cpu_baseline:
+            c32 = c16.astype(np.float32)
+            osearch.cpu_search_blas(q16, c32, k)  # warm-up
+            times = []
+            budget = time.perf_counter() + 20.0
+            while len(times) < 5 and (len(times) < 2 or time.perf_counter() < budget):
+                t = time.perf_counter()
+                osearch.cpu_search_blas(q16, c32, k)
+                times.append(time.perf_counter() - t)
+            med = float(np.median(times))
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count()
+            result["cpu_baseline"] = {
+                "value": round(B / med, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+                "sample": f"{len(times)} full batches of the same workload ({rows} x {dim}, batch {B}, "
+                          f"top-{k}); numpy float32 BLAS matmul + argpartition (oracle/search.py "
+                          f"cpu_search_blas), median {med * 1e3:.1f} ms/batch"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

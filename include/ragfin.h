@@ -1,0 +1,166 @@
+/*
+ * ragfin.h -- C ABI of libragfin_hip.so: the MI355X (gfx950) engine behind the
+ * vector-retrieval hot path of rag-fin.
+ *
+ * Every entry point replaces a call the reference makes into one of its two
+ * un-vendored dependencies (sentence-transformers, pymilvus -> Milvus server);
+ * the reference call site each one stands in for is cited as
+ * <file>:<line> relative to the reference tree.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, opaque handles; no C++/torch types cross the ABI.
+ *   - every function returns an int status (RF_OK == 0, negative on error);
+ *     rf_last_error() gives the message for the calling thread.
+ *   - the CALLER owns all device memory (corpus storage, workspaces, inputs,
+ *     outputs); the library owns only small host-side handles.  Nothing here
+ *     calls hipMalloc/hipFree, and nothing synchronises the host with the
+ *     stream: work is enqueued on `stream` (a hipStream_t passed as void*) in
+ *     order, so a caller may capture it into a hipGraph.
+ *   - device pointers must be 16-byte aligned.
+ */
+#ifndef RAGFIN_H
+#define RAGFIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_OK 0
+#define RF_ERR_INVALID (-1)    /* bad argument (null, misaligned, out of range) */
+#define RF_ERR_UNSUPPORTED (-2) /* dim / k / device not supported by the kernels */
+#define RF_ERR_CAPACITY (-3)   /* index full, or workspace/storage too small */
+#define RF_ERR_HIP (-4)        /* a HIP runtime call failed */
+#define RF_ERR_DEVICE (-5)     /* no gfx950 device */
+
+/* per-query flag bits written by rf_search into flags_dev */
+#define RF_FLAG_CAND_OVERFLOW 1u /* candidate buffer overflowed: result not proven exact */
+#define RF_FLAG_TIE_OVERFLOW 2u  /* more near-ties than the rescoring set holds */
+
+#define RF_MAX_K 64      /* largest top-k the fused scan path serves */
+#define RF_QCHUNK 64     /* queries per corpus sweep */
+
+typedef struct rf_index rf_index_t;
+typedef struct rf_encoder rf_encoder_t;
+
+/* ---- library ---------------------------------------------------------- */
+int rf_version(void);
+const char* rf_last_error(void);
+/* RF_OK when `device` is a gfx950 part the kernels were built for. */
+int rf_device_check(int device);
+
+/* ---- corpus index: replaces the Milvus collection -----------------------
+ * Reference: schema + index build "chunking_storing (1).py":14-29 (FLOAT_VECTOR
+ * dim 384, COSINE); the vectors live here as fp16 in an MFMA-fragment tiled
+ * layout, scalar fields stay host-side in Python. */
+size_t rf_index_storage_bytes(int dim, int64_t capacity_rows);
+int rf_index_create(rf_index_t** out, int dim, int64_t capacity_rows,
+                    void* storage_dev, size_t storage_bytes, int device);
+int rf_index_destroy(rf_index_t* ix);
+/* Collection.insert/flush/load -- "chunking_storing (1).py":383-396.
+ * rows_dev: fp16 [n, dim] row-major.  Appends n rows (ids size .. size+n-1). */
+int rf_index_add_f16(rf_index_t* ix, const void* rows_dev, int64_t n, void* stream);
+/* Collection.num_entities -- vector_rag_mcp/main.py:113,120,164 */
+int64_t rf_index_size(const rf_index_t* ix);
+int rf_index_dim(const rf_index_t* ix);
+/* drop + recreate -- "chunking_storing (1).py":25-28 */
+int rf_index_reset(rf_index_t* ix, void* stream);
+/* Collection.query(expr="id in [...]") vector fetch -- graph_cons.py:308-311.
+ * rows_dev: int64 [n] row numbers; out_dev: fp16 [n, dim] row-major. */
+int rf_index_get_rows_f16(const rf_index_t* ix, const int64_t* rows_dev, int64_t n,
+                          void* out_dev, void* stream);
+/* fp32 [n, dim] -> L2-normalised fp16 [n, dim] (what COSINE needs so that the
+ * scan can use the inner product).  Reference: the normalise step of
+ * SentenceTransformer.encode feeding Collection.insert, same file :380-394. */
+int rf_normalize_f32_to_f16(const float* in_dev, int64_t n, int dim, int normalize,
+                            void* out_dev, void* stream);
+
+/* ---- search: replaces Collection.search(..., COSINE, top_k) ---------------
+ * Reference: vector_rag_mcp/main.py:51-57, retrieve.py:28-34,
+ * "chunking_storing (1).py":411-417, graph_cons.py:275-281.
+ *
+ * q_dev      fp16 [B, dim] row-major queries (L2-normalised by the caller for
+ *            COSINE; raw for inner product)
+ * scores_dev fp32 [B, k]   score of rank j (descending), -inf past the end
+ * ids_dev    int64 [B, k]  row id + id_base, -1 past the end
+ * exact_dev  fp64 [B, k]   (nullable) the un-rounded ranking scores, used by
+ *            the cross-shard merge
+ * flags_dev  uint32 [B]    RF_FLAG_* bits; 0 means the result is proven equal
+ *            to the exact ranking by (score desc, id asc)
+ */
+size_t rf_search_workspace_bytes(const rf_index_t* ix);
+int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_base,
+              float* scores_dev, int64_t* ids_dev, double* exact_dev,
+              uint32_t* flags_dev, void* workspace_dev, size_t workspace_bytes,
+              void* stream);
+/* Profiling variant of rf_search for the first min(B, RF_QCHUNK) queries: same
+ * launches, with HIP events around each stage.  SYNCHRONISES the stream.
+ * stage_ms_host (host memory) receives {sample scan, threshold, emit scan, merge}
+ * in milliseconds.  Measurement hook for bench.py; no reference counterpart. */
+int rf_search_profile(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_base,
+                      float* scores_dev, int64_t* ids_dev, double* exact_dev,
+                      uint32_t* flags_dev, void* workspace_dev, size_t workspace_bytes,
+                      void* stream, float* stage_ms_host);
+/* Slow, unconditionally exact path (fp64 scores of every row); used for the
+ * queries rf_search flagged.  Same outputs. */
+int rf_search_exhaustive(const rf_index_t* ix, const void* q_dev, int B, int k,
+                         int64_t id_base, float* scores_dev, int64_t* ids_dev,
+                         double* exact_dev, void* workspace_dev, size_t workspace_bytes,
+                         void* stream);
+/* Cross-shard merge after the RCCL all-gather: in [W, B, k] (exact fp64, id
+ * int64) -> out [B, k] by (score desc, id asc).  New in this build (the
+ * reference is single-process); see SURVEY.md 8e. */
+int rf_merge_shards(const double* exact_dev, const int64_t* ids_dev, int W, int B, int k,
+                    float* scores_out_dev, int64_t* ids_out_dev, void* stream);
+/* Test hook: raw MFMA scan scores fp32 [B, n] for the first n rows. */
+int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,
+                    float* out_dev, void* stream);
+
+/* ---- embedder: replaces SentenceTransformer('all-MiniLM-L6-v2').encode ----
+ * Reference: vector_rag_mcp/main.py:41,50; retrieve.py:14,27;
+ * "chunking_storing (1).py":8,380,408. */
+typedef struct rf_encoder_config {
+  int32_t vocab_size, hidden, layers, heads, intermediate, max_position, type_vocab;
+  float ln_eps;
+} rf_encoder_config;
+
+/* All pointers are device fp16 unless noted; per-layer arrays are
+ * [layers] x tensor, contiguous.  Linear weights are stored [out, in]
+ * (PyTorch nn.Linear layout). */
+typedef struct rf_encoder_weights {
+  const void* word_emb;   /* [vocab, H] */
+  const void* pos_emb;    /* [max_position, H] */
+  const void* type_emb;   /* [type_vocab, H] */
+  const void* emb_ln_g;   /* [H] */
+  const void* emb_ln_b;   /* [H] */
+  const void* qkv_w;      /* [L, 3H, H]  (q;k;v stacked on the out axis) */
+  const void* qkv_b;      /* [L, 3H] */
+  const void* ao_w;       /* [L, H, H] */
+  const void* ao_b;       /* [L, H] */
+  const void* ln1_g;      /* [L, H] */
+  const void* ln1_b;      /* [L, H] */
+  const void* ff1_w;      /* [L, I, H] */
+  const void* ff1_b;      /* [L, I] */
+  const void* ff2_w;      /* [L, H, I] */
+  const void* ff2_b;      /* [L, H] */
+  const void* ln2_g;      /* [L, H] */
+  const void* ln2_b;      /* [L, H] */
+} rf_encoder_weights;
+
+int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cfg,
+                      const rf_encoder_weights* w, int device);
+int rf_encoder_destroy(rf_encoder_t* enc);
+size_t rf_encode_workspace_bytes(const rf_encoder_t* enc, int B, int T);
+/* ids_dev int32 [B, T] (padded), lens_dev int32 [B] (valid tokens per row).
+ * out_f16_dev fp16 [B, H] and/or out_f32_dev fp32 [B, H] (either nullable):
+ * masked mean-pool + L2-normalise of the last hidden state. */
+int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev,
+              int B, int T, void* out_f16_dev, float* out_f32_dev,
+              void* workspace_dev, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAGFIN_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of libragfin_hip.so (include/ragfin.h).
+
+There is no CPU fallback: if the library cannot be loaded, or a call returns a
+non-zero status, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_uint32, c_void_p)
+
+from . import build as _build
+
+RF_OK = 0
+RF_MAX_K = 64
+RF_QCHUNK = 64
+RF_FLAG_CAND_OVERFLOW = 1
+RF_FLAG_TIE_OVERFLOW = 2
+
+
+class RagfinError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libragfin_hip error {code}: {msg}")
+        self.code = code
+
+
+class EncoderConfig(Structure):
+    _fields_ = [("vocab_size", c_int32), ("hidden", c_int32), ("layers", c_int32),
+                ("heads", c_int32), ("intermediate", c_int32), ("max_position", c_int32),
+                ("type_vocab", c_int32), ("ln_eps", c_float)]
+
+
+ENCODER_WEIGHT_FIELDS = ["word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "qkv_w",
+                         "qkv_b", "ao_w", "ao_b", "ln1_g", "ln1_b", "ff1_w", "ff1_b", "ff2_w",
+                         "ff2_b", "ln2_g", "ln2_b"]
+
+
+class EncoderWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in ENCODER_WEIGHT_FIELDS]
+
+
+# name -> (restype, argtypes); every symbol include/ragfin.h declares
+SIGNATURES = {
+    "rf_version": (c_int, []),
+    "rf_last_error": (c_char_p, []),
+    "rf_device_check": (c_int, [c_int]),
+    "rf_index_storage_bytes": (c_size_t, [c_int, c_int64]),
+    "rf_index_create": (c_int, [POINTER(c_void_p), c_int, c_int64, c_void_p, c_size_t, c_int]),
+    "rf_index_destroy": (c_int, [c_void_p]),
+    "rf_index_add_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "rf_index_size": (c_int64, [c_void_p]),
+    "rf_index_dim": (c_int, [c_void_p]),
+    "rf_index_reset": (c_int, [c_void_p, c_void_p]),
+    "rf_index_get_rows_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "rf_normalize_f32_to_f16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "rf_search_workspace_bytes": (c_size_t, [c_void_p]),
+    "rf_search": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rf_search_profile": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                  POINTER(c_float)]),
+    "rf_search_exhaustive": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rf_merge_shards": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                c_void_p]),
+    "rf_debug_scores": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "rf_encoder_create": (c_int, [POINTER(c_void_p), POINTER(EncoderConfig),
+                                  POINTER(EncoderWeights), c_int]),
+    "rf_encoder_destroy": (c_int, [c_void_p]),
+    "rf_encode_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "rf_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                          c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB_PATH
+
+
+def load_library() -> ctypes.CDLL:
+    """Load (building first if the .so is absent and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        _build.build_lib()  # raises if hipcc is missing -- no fallback
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != RF_OK:
+        msg = load_library().rf_last_error()
+        raise RagfinError(code, msg.decode() if msg else "")
+
+
+def current_stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

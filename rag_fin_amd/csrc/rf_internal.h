@@ -1,0 +1,95 @@
+// Internal declarations shared by the HIP translation units of libragfin_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/ragfin.h"
+
+// ---- tiled corpus layout ---------------------------------------------------
+// The corpus is stored as 32-row blocks.  Block b holds KS = dim/16 "fragments"
+// of 1 KiB; fragment kk is exactly the A operand of one
+// v_mfma_f32_32x32x16_f16: lane l (r = l & 31, h = l >> 5) owns the 16 bytes
+// row[32 b + r][16 kk + 8 h .. +8).  One wave-wide 16-byte load therefore reads
+// 1 KiB of contiguous HBM straight into MFMA operand registers.
+#define RF_BLOCK_ROWS 32
+#define RF_FRAG_BYTES 1024
+
+__host__ __device__ inline size_t rf_chunk_index(int64_t row, int chunk, int KS) {
+  // index (in uint4 units) of 16-byte chunk `chunk` (dims 8*chunk..+8) of `row`
+  const int64_t b = row >> 5;
+  const int r = (int)(row & 31);
+  return ((size_t)b * KS + (chunk >> 1)) * 64 + (size_t)((chunk & 1) * 32 + r);
+}
+
+struct rf_index {
+  int dim;
+  int KS;              // dim / 16
+  int device;
+  int64_t capacity;    // rows
+  int64_t size;        // rows (host-side counter; adds are stream-ordered)
+  uint4* tiles;        // device: capacity_blocks * KS * 64 uint4
+  uint32_t* max_norm2; // device: bits of max squared row norm (float >= 0)
+  size_t storage_bytes;
+};
+
+// per-query candidate capacity of the fused scan
+#define RF_CAND_CAP 8192
+// rows below which the sample pass is skipped (every row becomes a candidate)
+#define RF_SMALL_ROWS 8192
+// partition maxima per query produced by the sample pass (one per workgroup)
+#define RF_SAMPLE_WGS 256
+// rescoring-set capacity per query
+#define RF_RESCORE_CAP 256
+
+struct rf_workspace {
+  float* thr;          // [64]
+  float* eps;          // [64]
+  uint32_t* cand_cnt;  // [64]
+  float* pmax;         // [64][RF_SAMPLE_WGS]
+  uint2* cand;         // [64][RF_CAND_CAP]  {row, score bits}
+  // exhaustive path
+  double* ex_score;    // [RF_EX_LISTS][RF_MAX_K]
+  int64_t* ex_row;     // [RF_EX_LISTS][RF_MAX_K]
+};
+#define RF_EX_WGS 256
+
+void rf_set_error(const char* fmt, ...);
+#define RF_HIP(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      rf_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                   __LINE__);                                                     \
+      return RF_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+
+// scan.hip
+int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_workspace& ws,
+                     int* P_out, hipStream_t st);
+int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_workspace& ws,
+                   hipStream_t st);
+int rf_launch_debug_scores(const rf_index* ix, const void* q, int B, int64_t n, float* out,
+                           hipStream_t st);
+int rf_scan_supported_dim(int dim);
+// merge.hip
+int rf_launch_threshold(const rf_index* ix, const void* q, int B, int k, int P,
+                        const rf_workspace& ws, hipStream_t st);
+int rf_launch_merge(const rf_index* ix, const void* q, int B, int k, int64_t id_base,
+                    const rf_workspace& ws, float* scores, int64_t* ids, double* exact,
+                    uint32_t* flags, hipStream_t st);
+int rf_launch_exhaustive(const rf_index* ix, const void* q, int B, int k, int64_t id_base,
+                         const rf_workspace& ws, float* scores, int64_t* ids, double* exact,
+                         hipStream_t st);
+int rf_launch_merge_shards(const double* exact, const int64_t* ids, int W, int B, int k,
+                           float* scores_out, int64_t* ids_out, hipStream_t st);
+
+// order-preserving map float -> uint32 (larger float <=> larger uint)
+__host__ __device__ inline uint32_t rf_f2ord(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float rf_ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __builtin_bit_cast(float, u);
+}

@@ -1,0 +1,405 @@
+// Streaming query x corpus scan on the matrix cores with a fused top-k filter.
+// This is the arithmetic Milvus performs for the reference's
+// Collection.search(..., {"metric_type": "COSINE"}, top_k)
+// (vector_rag_mcp/main.py:51-57, retrieve.py:28-34), restated for gfx950:
+//
+//   * the corpus lives in HBM as 32-row blocks of KS = dim/16 MFMA A-fragments
+//     (rf_internal.h); a wave streams a block with KS 1-KiB loads that land
+//     directly in the operand registers of v_mfma_f32_32x32x16_f16 -- no LDS
+//     round trip, no bank conflicts, every byte read exactly once;
+//   * the (<= 64) queries of the sweep sit in LDS in B-fragment order and are
+//     re-read per k-step (48 KB at dim 384);
+//   * each lane owns ONE query column of the 32x32 result, so the top-k filter
+//     is a lane-local compare against that query's threshold;
+//   * the loads form a register ring: fragment t+R is requested right after
+//     fragment t has been consumed, so every wave keeps R KiB (24 KiB at dim
+//     384) in flight across block boundaries and filter work.
+//
+// Two filters share the loop:
+//   MODE_SAMPLE  running max per lane over a strided sample of blocks ->
+//                one partition maximum per workgroup and query.  The k-th
+//                largest of those maxima is a lower bound of the final k-th
+//                best score (merge.hip turns it into the emit threshold).
+//   MODE_EMIT    every score >= threshold is appended to that query's
+//                candidate list (wave-level ballot compaction into LDS,
+//                flushed with one global atomic per entry).
+#include "rf_internal.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+enum { MODE_SAMPLE = 0, MODE_EMIT = 1 };
+
+#define SCAP 128  // per-wave LDS staging entries (>= 64)
+
+struct ScanParams {
+  const uint4* corpus;   // tiled
+  const _Float16* q;     // row-major [B, dim]
+  int B;
+  uint32_t n_rows;
+  uint32_t n_work;       // work items (blocks) for this launch
+  uint32_t bstride;      // corpus block index = work index * bstride
+  const float* thr;      // [64]
+  uint32_t* cand_cnt;    // [64]
+  uint2* cand;           // [64][cap]
+  uint32_t cap;
+  float* pmax;           // [64][P]
+  int P;
+};
+
+template <int KS>
+struct RingOf {
+  static constexpr int R = (KS <= 24) ? KS : 16;  // must divide KS
+};
+
+__device__ __forceinline__ u32x4 ld_frag(const uint4* p) {
+  return __builtin_nontemporal_load((const u32x4*)p);
+}
+
+__device__ __forceinline__ float max16(const f32x16& a) {
+  float m0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+  float m1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
+  float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
+  float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+  return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+}
+
+// row of accumulator register i within the 32-row block (lane half h)
+__device__ __forceinline__ uint32_t acc_row(int i, int h) {
+  return (uint32_t)((i & 3) + 8 * (i >> 2) + 4 * h);
+}
+
+struct EmitState {
+  uint32_t* s_row;     // [SCAP] per wave (LDS)
+  float* s_score;      // [SCAP]
+  uint32_t* s_q;       // [SCAP]
+  uint32_t cnt;        // wave-uniform
+};
+
+__device__ __forceinline__ void emit_flush(EmitState& es, const ScanParams& p, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  for (uint32_t i = lane; i < es.cnt; i += 64) {
+    const uint32_t q = es.s_q[i];
+    const uint32_t slot = atomicAdd(&p.cand_cnt[q], 1u);
+    if (slot < p.cap)
+      p.cand[(size_t)q * p.cap + slot] =
+          make_uint2(es.s_row[i], __builtin_bit_cast(uint32_t, es.s_score[i]));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  es.cnt = 0;
+}
+
+template <int JB>
+__device__ __forceinline__ void emit_slow(const f32x16 (&acc)[JB], const float (&th)[JB],
+                                       uint32_t row0, int lane, EmitState& es,
+                                       const ScanParams& p) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int jb = 0; jb < JB; ++jb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float s = acc[jb][i];
+      const uint32_t row = row0 + acc_row(i, h);
+      const bool pass = (s >= th[jb]) && (row < p.n_rows);
+      const unsigned long long mask = __ballot(pass);
+      if (mask != 0ull) {
+        const uint32_t n = (uint32_t)__popcll(mask);
+        if (es.cnt + n > SCAP) emit_flush(es, p, lane);
+        if (pass) {
+          const uint32_t slot = es.cnt + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+          es.s_row[slot] = row;
+          es.s_score[slot] = s;
+          es.s_q[slot] = (uint32_t)(jb * 32 + (lane & 31));
+        }
+        es.cnt += n;
+      }
+    }
+  }
+}
+
+template <int KS, int JB, int MODE, bool LAST>
+__device__ __forceinline__ void block_step(u32x4 (&ring)[RingOf<KS>::R], const uint4* cur,
+                                           const uint4* nxt, const u32x4* smemQ, int lane,
+                                           uint32_t row0, float (&th)[JB], float (&pm)[JB],
+                                           EmitState& es, const ScanParams& p) {
+  constexpr int R = RingOf<KS>::R;
+  // keep the query-fragment LDS reads inside the block: hoisted out of the
+  // block loop they would pin JB*KS*4 registers and spill
+  asm volatile("" ::: "memory");
+  f32x16 acc[JB];
+#pragma unroll
+  for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[jb][i] = 0.f;
+
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const half8 a = __builtin_bit_cast(half8, ring[kk % R]);
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+      const half8 b = __builtin_bit_cast(half8, smemQ[(jb * KS + kk) * 64 + lane]);
+      acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[jb], 0, 0, 0);
+    }
+    // re-arm this ring slot with the fragment R steps ahead
+    if (kk + R < KS) {
+      ring[kk % R] = ld_frag(cur + (kk + R) * 64);
+    } else if (!LAST) {
+      ring[kk % R] = ld_frag(nxt + (kk + R - KS) * 64);
+    }
+  }
+
+  if (MODE == MODE_SAMPLE) {
+    if (row0 + 32u > p.n_rows) {  // wave-uniform: only the corpus' last block
+      const int h = lane >> 5;
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (row0 + acc_row(i, h) >= p.n_rows) acc[jb][i] = -INFINITY;
+    }
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) pm[jb] = fmaxf(pm[jb], max16(acc[jb]));
+  } else {
+    bool hit = false;
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) hit |= (max16(acc[jb]) >= th[jb]);
+    if (__ballot(hit) != 0ull) emit_slow<JB>(acc, th, row0, lane, es, p);
+  }
+}
+
+template <int KS, int JB, int WAVES, int MODE>
+__global__ void __launch_bounds__(WAVES * 64, 2) k_scan(ScanParams p) {
+  constexpr int R = RingOf<KS>::R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* smemQ = (u32x4*)smem_raw;                                   // JB*KS*64 uint4
+  unsigned char* tail = smem_raw + (size_t)JB * KS * RF_FRAG_BYTES;  // per-mode scratch
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dim = KS * 16;
+
+  // stage the queries in B-fragment order: lane (j = l & 31, h = l >> 5) of
+  // fragment (jb, kk) holds q[32 jb + j][16 kk + 8 h .. +8)
+  for (int idx = tid; idx < JB * KS * 64; idx += WAVES * 64) {
+    const int l = idx & 63;
+    const int kk = (idx >> 6) % KS;
+    const int jb = idx / (64 * KS);
+    const int qi = jb * 32 + (l & 31);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (qi < p.B) v = *(const u32x4*)(p.q + (size_t)qi * dim + kk * 16 + (l >> 5) * 8);
+    smemQ[idx] = v;
+  }
+
+  float th[JB];
+  float pm[JB];
+#pragma unroll
+  for (int jb = 0; jb < JB; ++jb) {
+    pm[jb] = -INFINITY;
+    th[jb] = (MODE == MODE_EMIT) ? p.thr[jb * 32 + (lane & 31)] : 0.f;
+  }
+  EmitState es;
+  es.cnt = 0;
+  if (MODE == MODE_EMIT) {
+    es.s_row = (uint32_t*)tail + wave * SCAP;
+    es.s_score = (float*)((uint32_t*)tail + WAVES * SCAP) + wave * SCAP;
+    es.s_q = (uint32_t*)tail + 2 * WAVES * SCAP + wave * SCAP;
+  } else {
+    es.s_row = nullptr;
+    es.s_score = nullptr;
+    es.s_q = nullptr;
+  }
+  __syncthreads();
+
+  // work items w = gw, gw + W, ...  (one item = one 32-row block)
+  const uint32_t W = gridDim.x * WAVES;
+  const uint32_t gw = blockIdx.x * WAVES + wave;
+  const uint32_t cnt = (p.n_work > gw) ? (p.n_work - gw + W - 1) / W : 0u;
+
+  u32x4 ring[R];
+  if (cnt > 0) {
+    const uint4* src = p.corpus + (size_t)gw * p.bstride * (KS * 64) + lane;
+#pragma unroll
+    for (int s = 0; s < R; ++s) ring[s] = ld_frag(src + s * 64);
+
+    uint32_t w = gw;
+    for (uint32_t i = 0; i + 1 < cnt; ++i, w += W) {
+      const uint32_t b = w * p.bstride;
+      const uint4* cur = p.corpus + (size_t)b * (KS * 64) + lane;
+      const uint4* nxt = p.corpus + (size_t)(b + W * p.bstride) * (KS * 64) + lane;
+      block_step<KS, JB, MODE, false>(ring, cur, nxt, smemQ, lane, b * 32u, th, pm, es, p);
+    }
+    {
+      const uint32_t b = w * p.bstride;
+      const uint4* cur = p.corpus + (size_t)b * (KS * 64) + lane;
+      block_step<KS, JB, MODE, true>(ring, cur, cur, smemQ, lane, b * 32u, th, pm, es, p);
+    }
+  }
+
+  if (MODE == MODE_EMIT) {
+    if (es.cnt > 0) emit_flush(es, p, lane);
+  } else {
+    // workgroup partition maximum per query: max over waves and lane halves
+    float* red = (float*)tail;  // [WAVES*2][JB*32]
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+      red[(wave * 2 + (lane >> 5)) * (JB * 32) + jb * 32 + (lane & 31)] = pm[jb];
+    __syncthreads();
+    if (tid < JB * 32) {
+      float m = -INFINITY;
+      for (int s = 0; s < WAVES * 2; ++s) m = fmaxf(m, red[s * (JB * 32) + tid]);
+      p.pmax[(size_t)tid * p.P + blockIdx.x] = m;
+    }
+  }
+}
+
+// ---- raw score dump (test hook) ---------------------------------------------
+template <int KS>
+__global__ void __launch_bounds__(64) k_debug_scores(const uint4* corpus, const _Float16* q, int B,
+                                                      uint32_t n, float* out) {
+  // one wave per (block, 32-query group); plain loads, no ring
+  const int lane = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  const int jb = blockIdx.y;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int qi = jb * 32 + (lane & 31);
+  for (int kk = 0; kk < KS; ++kk) {
+    const uint4 av = corpus[((size_t)b * KS + kk) * 64 + lane];
+    uint4 bv = make_uint4(0, 0, 0, 0);
+    if (qi < B) bv = *(const uint4*)(q + (size_t)qi * (KS * 16) + kk * 16 + (lane >> 5) * 8);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, av),
+                                                 __builtin_bit_cast(half8, bv), acc, 0, 0, 0);
+  }
+  if (qi < B) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t row = b * 32u + acc_row(i, lane >> 5);
+      if (row < n) out[(size_t)qi * n + row] = acc[i];
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------
+template <int KS, int JB, int WAVES, int MODE>
+static int launch_scan(const ScanParams& p, int grid, hipStream_t st) {
+  size_t lds = (size_t)JB * KS * RF_FRAG_BYTES;
+  if (MODE == MODE_EMIT) lds += (size_t)3 * WAVES * SCAP * 4;
+  else lds += (size_t)WAVES * 2 * JB * 32 * 4;
+  auto kern = k_scan<KS, JB, WAVES, MODE>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    RF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, p);
+  RF_HIP(hipGetLastError());
+  return RF_OK;
+}
+
+template <int MODE>
+static int dispatch_scan(int KS, int JB, const ScanParams& p, int grid4, int grid8,
+                         hipStream_t st) {
+#define RF_CASE(ks, waves, grid)                                              \
+  case ks:                                                                    \
+    return JB == 1 ? launch_scan<ks, 1, waves, MODE>(p, grid, st)             \
+                   : launch_scan<ks, 2, waves, MODE>(p, grid, st);
+  switch (KS) {
+    RF_CASE(4, 4, grid4)
+    RF_CASE(8, 4, grid4)
+    RF_CASE(16, 4, grid4)
+    RF_CASE(24, 4, grid4)
+    RF_CASE(32, 4, grid4)
+    RF_CASE(48, 8, grid8)
+    RF_CASE(64, 8, grid8)
+    default:
+      break;
+  }
+#undef RF_CASE
+  rf_set_error("no scan kernel for dim %d", KS * 16);
+  return RF_ERR_UNSUPPORTED;
+}
+
+int rf_scan_supported_dim(int dim) {
+  switch (dim) {
+    case 64: case 128: case 256: case 384: case 512: case 768: case 1024:
+      return 1;
+    default:
+      return 0;
+  }
+}
+
+static inline int waves_per_wg(int KS) { return KS >= 48 ? 8 : 4; }
+static inline int wgs_per_cu(int KS) { return KS >= 48 ? 1 : 2; }
+
+int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_workspace& ws,
+                     int* P_out, hipStream_t st) {
+  const int KS = ix->KS;
+  const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
+  const int WAVES = waves_per_wg(KS);
+  // one workgroup per CU, SAMPLE_BPW blocks per wave, spread evenly over the corpus
+  const int SAMPLE_BPW = 2;
+  int grid = RF_SAMPLE_WGS;
+  if ((uint32_t)grid * WAVES > nblk) grid = (int)(nblk / WAVES);
+  if (grid < 1) grid = 1;
+  uint32_t n_work = (uint32_t)grid * WAVES * SAMPLE_BPW;
+  if (n_work > nblk) n_work = nblk;
+  const uint32_t bstride = nblk / n_work;  // >= 1
+  ScanParams p{};
+  p.corpus = ix->tiles;
+  p.q = (const _Float16*)q;
+  p.B = B;
+  p.n_rows = (uint32_t)ix->size;
+  p.n_work = n_work;
+  p.bstride = bstride;
+  p.pmax = ws.pmax;
+  p.P = grid;
+  *P_out = grid;
+  return dispatch_scan<MODE_SAMPLE>(KS, JB, p, grid, grid, st);
+}
+
+int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_workspace& ws,
+                   hipStream_t st) {
+  const int KS = ix->KS;
+  const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
+  const int WAVES = waves_per_wg(KS);
+  int grid = 256 * wgs_per_cu(KS);
+  const uint32_t need = (nblk + WAVES - 1) / WAVES;
+  if ((uint32_t)grid > need) grid = (int)need;
+  if (grid < 1) grid = 1;
+  ScanParams p{};
+  p.corpus = ix->tiles;
+  p.q = (const _Float16*)q;
+  p.B = B;
+  p.n_rows = (uint32_t)ix->size;
+  p.n_work = nblk;
+  p.bstride = 1;
+  p.thr = ws.thr;
+  p.cand_cnt = ws.cand_cnt;
+  p.cand = ws.cand;
+  p.cap = RF_CAND_CAP;
+  return dispatch_scan<MODE_EMIT>(KS, JB, p, grid, grid, st);
+}
+
+int rf_launch_debug_scores(const rf_index* ix, const void* q, int B, int64_t n, float* out,
+                           hipStream_t st) {
+  const uint32_t nblk = (uint32_t)((n + 31) / 32);
+  const dim3 grid(nblk, (B + 31) / 32);
+#define RF_DBG(ks)                                                                         \
+  case ks:                                                                                 \
+    hipLaunchKernelGGL(k_debug_scores<ks>, grid, dim3(64), 0, st, ix->tiles,               \
+                       (const _Float16*)q, B, (uint32_t)n, out);                           \
+    break;
+  switch (ix->KS) {
+    RF_DBG(4) RF_DBG(8) RF_DBG(16) RF_DBG(24) RF_DBG(32) RF_DBG(48) RF_DBG(64)
+    default:
+      rf_set_error("no debug kernel for dim %d", ix->dim);
+      return RF_ERR_UNSUPPORTED;
+  }
+#undef RF_DBG
+  RF_HIP(hipGetLastError());
+  return RF_OK;
+}

@@ -1,0 +1,85 @@
+"""Row-sharded search across the GPUs of one node (new in this
+build -- the reference is a single process talking to one Milvus server).
+
+One process per GPU.  Rank r holds the contiguous corpus rows
+[row_base, row_base + n_local) and scans them for the (replicated) query batch;
+the only exchange is ONE all-gather of the per-shard top-k
+  {fp64 ranking score, int64 global row id}[B, k]      (B=64, k=10: 10 KB/rank)
+over RCCL (torch.distributed backend "nccl"), followed by a merge by
+(score desc, id asc) on every rank.  Because the fp64 ranking scores are
+bit-reproducible per (query, row) and ids are global, the merged result is
+bit-identical to a single-GPU search over the concatenated corpus.
+
+The local scan and the merge go through a backend object; the product backend is
+libragfin_hip.so (HipShardBackend).  Tests inject a CPU backend to exercise the
+collective logic under gloo.
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+
+from . import _lib
+
+
+class HipShardBackend:
+    """Local scan = rf_search, merge = rf_merge_shards (both HIP)."""
+
+    def __init__(self, index):
+        self.index = index
+        self.device = index.device
+        self.lib = index.lib
+
+    def local_topk(self, q16, k: int, row_base: int):
+        scores, ids, exact, flags = self.index.search_raw(q16, k, id_base=row_base, want_exact=True)
+        return exact, ids, flags
+
+    def merge(self, exact_all, ids_all, k: int):
+        import torch
+        W, B, _ = exact_all.shape
+        scores = torch.empty((B, k), dtype=torch.float32, device=self.device)
+        ids = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.rf_merge_shards(c_void_p(exact_all.data_ptr()),
+                                                c_void_p(ids_all.data_ptr()), W, B, k,
+                                                c_void_p(scores.data_ptr()),
+                                                c_void_p(ids.data_ptr()),
+                                                _lib.current_stream_ptr()))
+        return scores, ids
+
+
+class ShardedSearcher:
+    def __init__(self, backend, row_base: int, group=None):
+        import torch.distributed as dist
+        self.backend = backend
+        self.row_base = int(row_base)
+        self.group = group
+        self.dist = dist
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    @staticmethod
+    def shard_bounds(n_total: int, world: int, rank: int):
+        """Contiguous row split; the first n_total % world ranks take one extra row."""
+        base, extra = divmod(n_total, world)
+        start = rank * base + min(rank, extra)
+        return start, start + base + (1 if rank < extra else 0)
+
+    def search(self, q16, k: int):
+        """Returns (scores f32 [B,k], global ids i64 [B,k], flags).  flags are the
+        local scan's per-query flags (non-zero -> caller re-runs those queries
+        through the exhaustive path before trusting the merge)."""
+        import torch
+        exact, ids, flags = self.backend.local_topk(q16, k, self.row_base)
+        if self.world == 1:
+            scores, gids = self.backend.merge(exact.unsqueeze(0).contiguous(),
+                                              ids.unsqueeze(0).contiguous(), k)
+            return scores, gids, flags
+        B = exact.shape[0]
+        # one collective: pack {score bits, id} as int64 [B, 2k]
+        packed = torch.cat([exact.view(torch.int64), ids], dim=1).contiguous()
+        gathered = torch.empty((self.world, B, 2 * k), dtype=torch.int64, device=packed.device)
+        self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        exact_all = gathered[:, :, :k].contiguous().view(torch.float64)
+        ids_all = gathered[:, :, k:].contiguous()
+        scores, gids = self.backend.merge(exact_all, ids_all, k)
+        return scores, gids, flags

@@ -113,7 +113,7 @@ __global__ void k_zero_u4(uint4* p, size_t n) {
 __global__ void k_tile_rows(const uint4* __restrict__ in, uint4* __restrict__ tiles,
                             int64_t first_row, int64_t n, int KS) {
   const int chunks = KS * 2;
-  const int64_t total = n * chunks;
+  const int64_t total = ((n + 31) / 32) * chunks * 32;  // (rowgroup, chunk, r) index space
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < total; i += stride) {

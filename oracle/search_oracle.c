@@ -7,9 +7,10 @@
  *   collection.search(q, "embedding", {"metric_type": "COSINE"}, top_k)
  * (vector_rag_mcp/main.py:51-57): every row scored, best `k` by descending score.
  *
- * Ranking contract: score = sequential float64 fma chain over d = 0..D-1 of
- * fp16 inputs; order by (score desc, row asc).  No -ffast-math: the loop over
- * rows may be vectorised, the chain over d may not be re-associated.
+ * Ranking contract (oracle/search.py): eight interleaved float64 fma chains
+ * (chain j takes d = j, j+8, ...), combined ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7));
+ * order by (score desc, row asc).  No -ffast-math: the loop over rows may be
+ * vectorised, the chains may not be re-associated.
  */
 #include <math.h>
 #include <stdint.h>
@@ -42,7 +43,7 @@ int oracle_search(const uint16_t* q, const uint16_t* c, int64_t B, int64_t N, in
   enum { TILE = 1024 };
   double* qd = (double*)malloc((size_t)D * sizeof(double));
   double* ct = (double*)malloc((size_t)D * TILE * sizeof(double)); /* [D][TILE] */
-  double* acc = (double*)malloc(TILE * sizeof(double));
+  double* acc = (double*)malloc((size_t)8 * TILE * sizeof(double)); /* [8][TILE] */
   if (!qd || !ct || !acc) { free(qd); free(ct); free(acc); return -1; }
   for (int64_t b = 0; b < B; ++b)
     for (int64_t j = 0; j < k; ++j) { out_s[b * k + j] = -INFINITY; out_i[b * k + j] = -1; }
@@ -55,12 +56,16 @@ int oracle_search(const uint16_t* q, const uint16_t* c, int64_t B, int64_t N, in
       for (int64_t d = 0; d < D; ++d) ct[d * TILE + r] = h2d(c[(r0 + r) * D + d]);
     for (int64_t b = 0; b < B; ++b) {
       for (int64_t d = 0; d < D; ++d) qd[d] = h2d(q[b * D + d]);
-      for (int64_t r = 0; r < m; ++r) acc[r] = 0.0;
+      for (int64_t r = 0; r < 8 * TILE; ++r) acc[r] = 0.0;
       for (int64_t d = 0; d < D; ++d) {
         const double qv = qd[d];
         const double* col = ct + d * TILE;
-        for (int64_t r = 0; r < m; ++r) acc[r] = fma(qv, col[r], acc[r]);
+        double* pj = acc + (d & 7) * TILE; /* chain j = d mod 8 */
+        for (int64_t r = 0; r < m; ++r) pj[r] = fma(qv, col[r], pj[r]);
       }
+      for (int64_t r = 0; r < m; ++r)
+        acc[r] = ((acc[r] + acc[TILE + r]) + (acc[2 * TILE + r] + acc[3 * TILE + r])) +
+                 ((acc[4 * TILE + r] + acc[5 * TILE + r]) + (acc[6 * TILE + r] + acc[7 * TILE + r]));
       double* ls = out_s + b * k;
       int64_t* li = out_i + b * k;
       for (int64_t r = 0; r < m; ++r) {

@@ -14,9 +14,9 @@ static size_t carve(unsigned char* base, rf_workspace* ws) {
   };
   float* thr = (float*)take(RF_QCHUNK * sizeof(float));
   float* eps = (float*)take(RF_QCHUNK * sizeof(float));
-  uint32_t* cnt = (uint32_t*)take(RF_QCHUNK * sizeof(uint32_t));
+  uint32_t* cnt = (uint32_t*)take((size_t)RF_QCHUNK * RF_CAND_SHARDS * sizeof(uint32_t));
   float* pmax = (float*)take((size_t)RF_QCHUNK * RF_SAMPLE_WGS * sizeof(float));
-  uint2* cand = (uint2*)take((size_t)RF_QCHUNK * RF_CAND_CAP * sizeof(uint2));
+  uint2* cand = (uint2*)take((size_t)RF_QCHUNK * RF_CAND_SHARDS * RF_SHARD_CAP * sizeof(uint2));
   double* exs = (double*)take((size_t)RF_QCHUNK * RF_EX_WGS * RF_MAX_K * sizeof(double));
   int64_t* exr = (int64_t*)take((size_t)RF_QCHUNK * RF_EX_WGS * RF_MAX_K * sizeof(int64_t));
   if (ws) {

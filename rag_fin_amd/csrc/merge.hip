@@ -4,9 +4,10 @@
 // (vector_rag_mcp/main.py:51-70): the k best rows by descending score.
 //
 // Ranking contract (mirrored by oracle/search.py): the score of (query, row)
-// is the fp64 value obtained by accumulating q[d]*c[d] for d = 0..dim-1 in that
-// order with one fused multiply-add per step (products of two fp16 values are
-// exact in fp64); rows are ranked by (score descending, row id ascending).
+// is the fp64 value p = ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) where chain
+// p_j = sum over d = j, j+8, j+16, ... (ascending) of q[d]*c[d], one fused
+// multiply-add per step (products of two fp16 values are exact in fp64); rows
+// are ranked by (score descending, row id ascending).
 // The MFMA scan only nominates candidates; every returned score comes from the
 // fp64 chain, so ids and ranks are bit-reproducible on the CPU.
 #include "rf_internal.h"
@@ -14,37 +15,61 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Wave-wide reductions on the DPP network (row_shr 1/2/4/8, row_bcast 15/31):
+// six VALU-rate steps instead of six LDS-crossbar shuffles.  The full result
+// lands in lane 63 and is broadcast with readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_keep(uint32_t v) {
+  // lanes without a valid source (or in a masked row) keep their own value
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ float wave_max_f(float v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+#define RF_STEP(ctrl, rm) \
+  v = fmaxf(v, __builtin_bit_cast(float, dpp_keep<ctrl, rm>(__builtin_bit_cast(uint32_t, v))));
+  RF_STEP(0x111, 0xF) RF_STEP(0x112, 0xF) RF_STEP(0x114, 0xF) RF_STEP(0x118, 0xF)
+  RF_STEP(0x142, 0xA) RF_STEP(0x143, 0xC)
+#undef RF_STEP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_sum_f(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, o);
-    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), o);
-    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
-    v = w > v ? w : v;
+#define RF_STEP(ctrl, rm)                                                           \
+  {                                                                                 \
+    const uint32_t lo = dpp_keep<ctrl, rm>((uint32_t)v);                            \
+    const uint32_t hi = dpp_keep<ctrl, rm>((uint32_t)(v >> 32));                    \
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo;               \
+    v = w > v ? w : v;                                                              \
   }
-  return v;
+  RF_STEP(0x111, 0xF) RF_STEP(0x112, 0xF) RF_STEP(0x114, 0xF) RF_STEP(0x118, 0xF)
+  RF_STEP(0x142, 0xA) RF_STEP(0x143, 0xC)
+#undef RF_STEP
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
-// fp64 ranking score: sequential fused multiply-add chain over d = 0..dim-1.
+// fp64 ranking score of the contract: eight interleaved chains (chain j takes
+// dims d = j mod 8, ascending, one fma per step) combined by a pairwise tree.
+__device__ __forceinline__ double tree8(const double (&p)[8]) {
+  return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+}
 __device__ __forceinline__ double exact_dot(const _Float16* __restrict__ qrow,
                                             const uint4* __restrict__ tiles, int64_t row, int KS) {
-  double acc = 0.0;
+  double p[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = 0.0;
   for (int c = 0; c < 2 * KS; ++c) {
     const uint4 cv = tiles[rf_chunk_index(row, c, KS)];
     const uint4 qv = *(const uint4*)(qrow + 8 * c);
     const half8 ch = __builtin_bit_cast(half8, cv);
     const half8 qh = __builtin_bit_cast(half8, qv);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc = fma((double)qh[j], (double)ch[j], acc);
+    for (int j = 0; j < 8; ++j) p[j] = fma((double)qh[j], (double)ch[j], p[j]);
   }
-  return acc;
+  return tree8(p);
 }
 
 // (score desc, row asc): is (s1, r1) ranked strictly before (s2, r2)?
@@ -112,18 +137,39 @@ __global__ void __launch_bounds__(64) k_threshold(const _Float16* __restrict__ q
   if (lane == 0) {
     thr[qi] = t;
     eps_out[qi] = eps;
-    cand_cnt[qi] = 0u;
   }
+  if (lane < RF_CAND_SHARDS) cand_cnt[qi * RF_CAND_SHARDS + lane] = 0u;
 }
 
 // ---- candidate merge + exact rescoring --------------------------------------------
+// One workgroup per query:
+//   1. find the k-th largest candidate by (MFMA score, row): rank counting over
+//      LDS-broadcast keys when there are <= 1024 candidates (the usual ~150-300),
+//      extraction rounds otherwise (small corpora, where every row is a candidate);
+//   2. compact the rescoring set R = {MFMA score >= kth - 2 eps} (k + a few rows);
+//   3. stage the rows of R in LDS with all 256 threads (one HBM latency instead
+//      of one per 16-byte chunk), then one thread per row runs the fp64 chain;
+//   4. rank R by (exact desc, row asc) and write the top-k.
 #define MERGE_THREADS 256
 #define MERGE_PER_THREAD (RF_CAND_CAP / MERGE_THREADS)
+#define MERGE_RANK_MAX 1024
+#define MERGE_STAGE_ROWS 32
 
 __device__ __forceinline__ unsigned long long cand_key(uint2 e) {
   // larger key <=> (higher score, then lower row)
   return ((unsigned long long)rf_f2ord(__builtin_bit_cast(float, e.y)) << 32) |
          (unsigned long long)(0xFFFFFFFFu - e.x);
+}
+__device__ __forceinline__ float key_score(unsigned long long key) {
+  return rf_ord2f((uint32_t)(key >> 32));
+}
+__device__ __forceinline__ uint32_t key_row(unsigned long long key) {
+  return 0xFFFFFFFFu - (uint32_t)key;
+}
+
+static size_t merge_lds_bytes(int dim) {
+  return (size_t)MERGE_RANK_MAX * 8 + (MERGE_THREADS / 64) * RF_MAX_K * 8 + RF_RESCORE_CAP * 8 +
+         RF_RESCORE_CAP * 4 + 64 + (size_t)dim * 8 + (size_t)MERGE_STAGE_ROWS * (dim * 2 + 16);
 }
 
 __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
@@ -131,95 +177,178 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
     int64_t id_base, const uint32_t* __restrict__ cand_cnt, const uint2* __restrict__ cand,
     uint32_t cap, const float* __restrict__ eps_in, float* __restrict__ scores,
     int64_t* __restrict__ ids, double* __restrict__ exact, uint32_t* __restrict__ flags) {
-  __shared__ unsigned long long wtop[MERGE_THREADS / 64][RF_MAX_K];
-  __shared__ double r_exact[RF_RESCORE_CAP];
-  __shared__ uint32_t r_row[RF_RESCORE_CAP];
-  __shared__ uint32_t r_cnt;
-  __shared__ float t_cut;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned long long* skeys = (unsigned long long*)lds;                       // [1024]
+  unsigned long long* wtop = skeys + MERGE_RANK_MAX;                          // [4][RF_MAX_K]
+  double* r_exact = (double*)(wtop + (MERGE_THREADS / 64) * RF_MAX_K);        // [RESCORE_CAP]
+  uint32_t* r_row = (uint32_t*)(r_exact + RF_RESCORE_CAP);                    // [RESCORE_CAP]
+  uint32_t* r_cnt = r_row + RF_RESCORE_CAP;                                   // misc: 16 words
+  float* t_cut = (float*)(r_cnt + 1);
+  double* qd = (double*)(r_cnt + 16);                                         // [dim]
+  uint4* srows = (uint4*)(qd + dim);                                          // [32][2 KS + 1]
+  const int srow_stride = 2 * KS + 1;
 
   const int qi = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const uint32_t total = cand_cnt[qi];
-  const uint32_t c = total < cap ? total : cap;
-  uint32_t fl = total > cap ? RF_FLAG_CAND_OVERFLOW : 0u;
+  // candidate lists of this query: RF_CAND_SHARDS lists of up to `cap` entries;
+  // global candidate index g -> (list s, entry g - off[s])
+  uint32_t off[RF_CAND_SHARDS + 1];
+  uint32_t fl = 0u;
+  off[0] = 0u;
+#pragma unroll
+  for (int s = 0; s < RF_CAND_SHARDS; ++s) {
+    const uint32_t n = cand_cnt[qi * RF_CAND_SHARDS + s];
+    if (n > cap) fl = RF_FLAG_CAND_OVERFLOW;
+    off[s + 1] = off[s] + (n < cap ? n : cap);
+  }
+  const uint32_t total = off[RF_CAND_SHARDS];
+  if (total > RF_CAND_CAP) fl = RF_FLAG_CAND_OVERFLOW;
+  const uint32_t c = total < RF_CAND_CAP ? total : RF_CAND_CAP;
   const int kk = (uint32_t)k < c ? k : (int)c;
-  const uint2* mine = cand + (size_t)qi * cap;
-  if (tid == 0) r_cnt = 0u;
+  const bool have_cut = kk > 0 && (uint32_t)k <= c;  // fewer than k candidates: rescore all
+  const uint2* lists = cand + (size_t)qi * RF_CAND_SHARDS * cap;
+  auto cand_at = [&](uint32_t g) -> uint2 {
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < RF_CAND_SHARDS; ++t) s += g >= off[t] ? 1 : 0;
+    return lists[(size_t)s * cap + (g - off[s])];
+  };
+  const float eps2 = 2.f * eps_in[qi];
+  if (tid == 0) {
+    *r_cnt = 0u;
+    *t_cut = -INFINITY;
+  }
+  for (int d = tid; d < dim; d += MERGE_THREADS) ((_Float16*)qd)[d] = q[(size_t)qi * dim + d];
 
-  // pass 1: kk-th largest candidate by (MFMA score, row) -- per wave, then across waves
-  unsigned long long key[MERGE_PER_THREAD];
+  if (c <= MERGE_RANK_MAX) {
+    // ---- pass 1a: rank counting ------------------------------------------------
+    unsigned long long key[MERGE_RANK_MAX / MERGE_THREADS];
 #pragma unroll
-  for (int i = 0; i < MERGE_PER_THREAD; ++i) {
-    const uint32_t idx = (uint32_t)tid + MERGE_THREADS * i;
-    key[i] = idx < c ? cand_key(mine[idx]) : 0ull;
-  }
-  for (int r = 0; r < kk; ++r) {
-    unsigned long long m = key[0];
-#pragma unroll
-    for (int i = 1; i < MERGE_PER_THREAD; ++i) m = key[i] > m ? key[i] : m;
-    const unsigned long long wm = wave_max_u64(m);
-    if (lane == 0) wtop[wave][r] = wm;
-    if (wm != 0ull && m == wm) {
-#pragma unroll
-      for (int i = 0; i < MERGE_PER_THREAD; ++i)
-        if (key[i] == wm) key[i] = 0ull;
+    for (int i = 0; i < MERGE_RANK_MAX / MERGE_THREADS; ++i) {
+      const uint32_t idx = (uint32_t)tid + MERGE_THREADS * i;
+      key[i] = idx < c ? cand_key(cand_at(idx)) : 0ull;
+      skeys[idx] = key[i];  // zero padding never outranks a real key
     }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    unsigned long long v[(MERGE_THREADS / 64 * RF_MAX_K + 63) / 64];
-    constexpr int NV = (MERGE_THREADS / 64 * RF_MAX_K + 63) / 64;
+    __syncthreads();
+    if (have_cut) {
+      uint32_t rank[MERGE_RANK_MAX / MERGE_THREADS];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int j = lane + 64 * i;  // j -> (wave j / kk, slot j % kk)
-      v[i] = (j < (MERGE_THREADS / 64) * kk) ? wtop[j / kk][j % kk] : 0ull;
+      for (int i = 0; i < MERGE_RANK_MAX / MERGE_THREADS; ++i) rank[i] = 0;
+      for (uint32_t j = 0; j < c; j += 8) {
+        unsigned long long o[8];  // same addresses in every lane: LDS broadcast, 8 in flight
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = skeys[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int i = 0; i < MERGE_RANK_MAX / MERGE_THREADS; ++i) rank[i] += o[u] > key[i] ? 1u : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < MERGE_RANK_MAX / MERGE_THREADS; ++i)
+        if (key[i] != 0ull && rank[i] == (uint32_t)(kk - 1)) *t_cut = key_score(key[i]) - eps2;
     }
-    unsigned long long kth = 0ull;
-    for (int r = 0; r < kk; ++r) {
-      unsigned long long m = v[0];
+    __syncthreads();
+    // ---- pass 2a: compact R from the LDS keys -----------------------------------
+    const float cut = *t_cut;
 #pragma unroll
-      for (int i = 1; i < NV; ++i) m = v[i] > m ? v[i] : m;
-      const unsigned long long wm = wave_max_u64(m);
-      kth = wm;
-      if (wm != 0ull && m == wm) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-          if (v[i] == wm) v[i] = 0ull;
+    for (int i = 0; i < MERGE_RANK_MAX / MERGE_THREADS; ++i) {
+      if (key[i] != 0ull && key_score(key[i]) >= cut) {
+        const uint32_t slot = atomicAdd(r_cnt, 1u);
+        if (slot < RF_RESCORE_CAP) r_row[slot] = key_row(key[i]);
       }
     }
-    if (lane == 0) {
-      // rescoring cut: every row of the exact top-k has MFMA score >= kth - 2 eps
-      float cut = -INFINITY;
-      if (kk > 0 && (uint32_t)k <= c) cut = rf_ord2f((uint32_t)(kth >> 32)) - 2.f * eps_in[qi];
-      t_cut = cut;
+  } else {
+    // ---- pass 1b: extraction rounds (per wave, then across waves) ---------------
+    unsigned long long key[MERGE_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < MERGE_PER_THREAD; ++i) {
+      const uint32_t idx = (uint32_t)tid + MERGE_THREADS * i;
+      key[i] = idx < c ? cand_key(cand_at(idx)) : 0ull;
+    }
+    for (int r = 0; r < kk; ++r) {
+      unsigned long long m = key[0];
+#pragma unroll
+      for (int i = 1; i < MERGE_PER_THREAD; ++i) m = key[i] > m ? key[i] : m;
+      const unsigned long long wm = wave_max_u64(m);
+      if (lane == 0) wtop[wave * RF_MAX_K + r] = wm;
+      if (wm != 0ull && m == wm) {
+#pragma unroll
+        for (int i = 0; i < MERGE_PER_THREAD; ++i)
+          if (key[i] == wm) key[i] = 0ull;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      constexpr int NV = (MERGE_THREADS / 64 * RF_MAX_K + 63) / 64;
+      unsigned long long v[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int j = lane + 64 * i;  // j -> (wave j / kk, slot j % kk)
+        v[i] = (kk > 0 && j < (MERGE_THREADS / 64) * kk) ? wtop[(j / kk) * RF_MAX_K + (j % kk)] : 0ull;
+      }
+      unsigned long long kth = 0ull;
+      for (int r = 0; r < kk; ++r) {
+        unsigned long long m = v[0];
+#pragma unroll
+        for (int i = 1; i < NV; ++i) m = v[i] > m ? v[i] : m;
+        const unsigned long long wm = wave_max_u64(m);
+        kth = wm;
+        if (wm != 0ull && m == wm) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i)
+            if (v[i] == wm) v[i] = 0ull;
+        }
+      }
+      if (lane == 0 && have_cut) *t_cut = key_score(kth) - eps2;
+    }
+    __syncthreads();
+    // ---- pass 2b: compact R from global ------------------------------------------
+    const float cut = *t_cut;
+    for (uint32_t idx = tid; idx < c; idx += MERGE_THREADS) {
+      const uint2 e = cand_at(idx);
+      if (__builtin_bit_cast(float, e.y) >= cut) {
+        const uint32_t slot = atomicAdd(r_cnt, 1u);
+        if (slot < RF_RESCORE_CAP) r_row[slot] = e.x;
+      }
     }
   }
   __syncthreads();
-
-  // pass 2: compact the rescoring set R = {score >= cut}
-  const float cut = t_cut;
-  for (uint32_t idx = tid; idx < c; idx += MERGE_THREADS) {
-    const uint2 e = mine[idx];
-    if (__builtin_bit_cast(float, e.y) >= cut) {
-      const uint32_t slot = atomicAdd(&r_cnt, 1u);
-      if (slot < RF_RESCORE_CAP) r_row[slot] = e.x;
-    }
-  }
-  __syncthreads();
-  uint32_t R = r_cnt;
+  uint32_t R = *r_cnt;
   if (R > RF_RESCORE_CAP) {
     fl |= RF_FLAG_TIE_OVERFLOW;
     R = RF_RESCORE_CAP;
   }
 
-  // pass 3: exact fp64 scores
-  for (uint32_t i = tid; i < R; i += MERGE_THREADS)
-    r_exact[i] = exact_dot(q + (size_t)qi * dim, tiles, (int64_t)r_row[i], KS);
-  __syncthreads();
+  // ---- pass 3: exact fp64 scores, rows staged through LDS ---------------------------
+  // 8 lanes per candidate: lane j owns chain j (dims j, j+8, ...); xor-shuffle tree.
+  const int chunks = 2 * KS;
+  const _Float16* qh = (const _Float16*)qd;  // query row as fp16 in LDS
+  for (uint32_t base = 0; base < R; base += MERGE_STAGE_ROWS) {
+    const uint32_t nb = (R - base) < MERGE_STAGE_ROWS ? (R - base) : MERGE_STAGE_ROWS;
+    for (uint32_t idx = tid; idx < nb * (uint32_t)chunks; idx += MERGE_THREADS) {
+      const uint32_t r = idx / chunks, ch = idx % chunks;
+      srows[r * srow_stride + ch] = tiles[rf_chunk_index((int64_t)r_row[base + r], (int)ch, KS)];
+    }
+    __syncthreads();
+    {
+      const uint32_t r = (uint32_t)tid >> 3;   // 32 candidates x 8 lanes = 256 threads
+      const int j = tid & 7;
+      const _Float16* row = (const _Float16*)(srows + (r < nb ? r : 0) * srow_stride);
+      double acc = 0.0;
+#pragma unroll 8
+      for (int ch = 0; ch < chunks; ++ch)
+        acc = fma((double)qh[8 * ch + j], (double)row[8 * ch + j], acc);
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 4);
+      if (j == 0 && r < nb) r_exact[base + r] = acc;
+    }
+    __syncthreads();
+  }
 
-  // pass 4: rank by (exact desc, row asc) and write
+  // ---- pass 4: rank by (exact desc, row asc) and write --------------------------------
   for (uint32_t i = tid; i < R; i += MERGE_THREADS) {
     const double s = r_exact[i];
     const uint32_t row = r_row[i];
@@ -241,7 +370,6 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
   }
   if (tid == 0 && flags) flags[qi] = fl;
 }
-
 // ---- exhaustive exact path ----------------------------------------------------------
 // Workgroup-level running top-k list (sorted, in LDS) updated 256 entries at a
 // time by rank counting.  Used for queries the fused path could not prove
@@ -400,8 +528,15 @@ int rf_launch_threshold(const rf_index* ix, const void* q, int B, int k, int P,
 int rf_launch_merge(const rf_index* ix, const void* q, int B, int k, int64_t id_base,
                     const rf_workspace& ws, float* scores, int64_t* ids, double* exact,
                     uint32_t* flags, hipStream_t st) {
-  hipLaunchKernelGGL(k_merge, dim3(B), dim3(MERGE_THREADS), 0, st, (const _Float16*)q, ix->dim,
-                     ix->KS, ix->tiles, k, id_base, ws.cand_cnt, ws.cand, (uint32_t)RF_CAND_CAP,
+  const size_t lds = merge_lds_bytes(ix->dim);
+  static size_t lds_attr = 0;
+  if (lds > lds_attr) {
+    RF_HIP(hipFuncSetAttribute((const void*)k_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+    lds_attr = lds;
+  }
+  hipLaunchKernelGGL(k_merge, dim3(B), dim3(MERGE_THREADS), lds, st, (const _Float16*)q, ix->dim,
+                     ix->KS, ix->tiles, k, id_base, ws.cand_cnt, ws.cand, (uint32_t)RF_SHARD_CAP,
                      ws.eps, scores, ids, exact, flags);
   RF_HIP(hipGetLastError());
   return RF_OK;

@@ -32,8 +32,11 @@ struct rf_index {
   size_t storage_bytes;
 };
 
-// per-query candidate capacity of the fused scan
+// per-query candidate capacity of the fused scan: RF_CAND_SHARDS lists (picked by
+// workgroup id) of RF_SHARD_CAP entries; the merge handles RF_CAND_CAP in total
 #define RF_CAND_CAP 8192
+#define RF_CAND_SHARDS 8
+#define RF_SHARD_CAP 2048
 // rows below which the sample pass is skipped (every row becomes a candidate)
 #define RF_SMALL_ROWS 8192
 // partition maxima per query produced by the sample pass (one per workgroup)
@@ -44,9 +47,9 @@ struct rf_index {
 struct rf_workspace {
   float* thr;          // [64]
   float* eps;          // [64]
-  uint32_t* cand_cnt;  // [64]
+  uint32_t* cand_cnt;  // [64][RF_CAND_SHARDS]
   float* pmax;         // [64][RF_SAMPLE_WGS]
-  uint2* cand;         // [64][RF_CAND_CAP]  {row, score bits}
+  uint2* cand;         // [64][RF_CAND_SHARDS][RF_SHARD_CAP]  {row, score bits}
   // exhaustive path
   double* ex_score;    // [RF_EX_LISTS][RF_MAX_K]
   int64_t* ex_row;     // [RF_EX_LISTS][RF_MAX_K]

@@ -24,6 +24,7 @@
 //                candidate list (wave-level ballot compaction into LDS,
 //                flushed with one global atomic per entry).
 #include "rf_internal.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,7 +32,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 enum { MODE_SAMPLE = 0, MODE_EMIT = 1 };
 
-#define SCAP 128  // per-wave LDS staging entries (>= 64)
+#define SCAP 64  // per-wave LDS staging entries (>= 64: one ballot round can add 64)
 
 struct ScanParams {
   const uint4* corpus;   // tiled
@@ -41,8 +42,8 @@ struct ScanParams {
   uint32_t n_work;       // work items (blocks) for this launch
   uint32_t bstride;      // corpus block index = work index * bstride
   const float* thr;      // [64]
-  uint32_t* cand_cnt;    // [64]
-  uint2* cand;           // [64][cap]
+  uint32_t* cand_cnt;    // [64][RF_CAND_SHARDS]
+  uint2* cand;           // [64][RF_CAND_SHARDS][cap]
   uint32_t cap;
   float* pmax;           // [64][P]
   int P;
@@ -81,9 +82,12 @@ __device__ __forceinline__ void emit_flush(EmitState& es, const ScanParams& p, i
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   for (uint32_t i = lane; i < es.cnt; i += 64) {
     const uint32_t q = es.s_q[i];
-    const uint32_t slot = atomicAdd(&p.cand_cnt[q], 1u);
+    // RF_CAND_SHARDS counters per query: same-address atomics serialise (~12 ns
+    // each), and most waves flush together at the end of the scan
+    const uint32_t list = q * RF_CAND_SHARDS + (blockIdx.x & (RF_CAND_SHARDS - 1));
+    const uint32_t slot = atomicAdd(&p.cand_cnt[list], 1u);
     if (slot < p.cap)
-      p.cand[(size_t)q * p.cap + slot] =
+      p.cand[(size_t)list * p.cap + slot] =
           make_uint2(es.s_row[i], __builtin_bit_cast(uint32_t, es.s_score[i]));
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -333,6 +337,11 @@ int rf_scan_supported_dim(int dim) {
 }
 
 static inline int waves_per_wg(int KS) { return KS >= 48 ? 8 : 4; }
+// tuning knobs (environment, read once): RF_SAMPLE_BPW, RF_EMIT_WGS_PER_CU
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
 static inline int wgs_per_cu(int KS) { return KS >= 48 ? 1 : 2; }
 
 int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_workspace& ws,
@@ -341,7 +350,7 @@ int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_
   const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
   const int WAVES = waves_per_wg(KS);
   // one workgroup per CU, SAMPLE_BPW blocks per wave, spread evenly over the corpus
-  const int SAMPLE_BPW = 2;
+  static const int SAMPLE_BPW = env_int("RF_SAMPLE_BPW", 2);
   int grid = RF_SAMPLE_WGS;
   if ((uint32_t)grid * WAVES > nblk) grid = (int)(nblk / WAVES);
   if (grid < 1) grid = 1;
@@ -366,7 +375,8 @@ int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_wo
   const int KS = ix->KS;
   const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
   const int WAVES = waves_per_wg(KS);
-  int grid = 256 * wgs_per_cu(KS);
+  static const int wgs_env = env_int("RF_EMIT_WGS_PER_CU", 0);
+  int grid = 256 * (wgs_env > 0 ? wgs_env : wgs_per_cu(KS));
   const uint32_t need = (nblk + WAVES - 1) / WAVES;
   if ((uint32_t)grid > need) grid = (int)need;
   if (grid < 1) grid = 1;
@@ -380,7 +390,7 @@ int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_wo
   p.thr = ws.thr;
   p.cand_cnt = ws.cand_cnt;
   p.cand = ws.cand;
-  p.cap = RF_CAND_CAP;
+  p.cap = RF_SHARD_CAP;
   return dispatch_scan<MODE_EMIT>(KS, JB, p, grid, grid, st);
 }
 

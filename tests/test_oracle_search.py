@@ -13,9 +13,10 @@ def brute(q16, c16, k):
     for q in q16.astype(np.float64):
         scored = []
         for r, c in enumerate(c16.astype(np.float64)):
-            acc = 0.0
-            for a, b in zip(q, c):
-                acc = acc + a * b   # product exact in f64 -> same as fma
+            p = [0.0] * 8
+            for d, (a, b) in enumerate(zip(q, c)):
+                p[d % 8] = p[d % 8] + a * b   # product exact in f64 -> same as fma
+            acc = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))
             scored.append((-acc, r))
         scored.sort()
         out.append(scored[:k])

@@ -149,8 +149,16 @@ typedef struct rf_encoder_weights {
   const void* ln2_b;      /* [L, H] */
 } rf_encoder_weights;
 
+/* Bytes of caller-owned device storage the encoder needs for its MFMA-tiled copy
+ * of the four Linear weights per layer (0 if cfg is unsupported). */
+size_t rf_encoder_storage_bytes(const rf_encoder_config* cfg);
+/* Tiles the Linear weights into storage_dev on `stream` and keeps the remaining
+ * pointers of `w` (embeddings, biases, LayerNorm) -- the caller keeps those
+ * tensors alive for the encoder's lifetime.  Supported: hidden == 384,
+ * head_dim == 32, intermediate % 384 == 0 (the all-MiniLM-L{6,12}-H384 family). */
 int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cfg,
-                      const rf_encoder_weights* w, int device);
+                      const rf_encoder_weights* w, void* storage_dev, size_t storage_bytes,
+                      int device, void* stream);
 int rf_encoder_destroy(rf_encoder_t* enc);
 size_t rf_encode_workspace_bytes(const rf_encoder_t* enc, int B, int T);
 /* ids_dev int32 [B, T] (padded), lens_dev int32 [B] (valid tokens per row).

@@ -65,8 +65,9 @@ SIGNATURES = {
     "rf_merge_shards": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p]),
     "rf_debug_scores": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "rf_encoder_storage_bytes": (c_size_t, [POINTER(EncoderConfig)]),
     "rf_encoder_create": (c_int, [POINTER(c_void_p), POINTER(EncoderConfig),
-                                  POINTER(EncoderWeights), c_int]),
+                                  POINTER(EncoderWeights), c_void_p, c_size_t, c_int, c_void_p]),
     "rf_encoder_destroy": (c_int, [c_void_p]),
     "rf_encode_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "rf_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,

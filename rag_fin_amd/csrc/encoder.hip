@@ -1,18 +1,524 @@
-// Embedder entry points (filled in by the encoder kernels; this revision only
-// reserves the ABI so that the library exports every symbol of ragfin.h).
+// Sentence-embedder forward pass (BERT encoder + mean-pool + L2-normalise) for the
+// all-MiniLM-L6-v2 family (hidden 384, 12 heads x 32), hand-written for gfx950.
+// Stands in for SentenceTransformer('all-MiniLM-L6-v2').encode(...)
+// (vector_rag_mcp/main.py:41,50; retrieve.py:14,27; "chunking_storing (1).py":8,380).
+//
+// Data layout
+//   * tokens are PACKED: only the lens[b] valid tokens of each sequence occupy
+//     rows of the activation matrices ([M, 384] fp16 row-major, M = sum lens), so
+//     padding costs nothing and needs no attention mask;
+//   * every Linear weight [out, in] is stored once in the same 32-row x 16-k MFMA
+//     fragment tiling as the corpus (rf_internal.h): one 1-KiB wave load = one
+//     A operand of v_mfma_f32_32x32x16_f16.
+//
+// Kernels
+//   k_tok_offsets   lens -> packed row offsets
+//   k_embed_ln      word + position + type embedding gather, LayerNorm        (K1)
+//   k_linear<EPI>   Y^T = W X^T on the matrix cores: a workgroup owns 32 tokens x
+//                   384 output features (4 waves x 96); epilogues fused:
+//                   bias (QKV, K2) | bias+GELU (K5) | bias+residual+LayerNorm (K4, K6)
+//   k_attention     softmax(Q K^T / sqrt(32)) V per (sequence, head), online
+//                   softmax in fp32 on the vector ALU (< 2 % of the model FLOPs) (K3)
+//   k_pool_norm     mean over the sequence, L2-normalise                      (K7)
 #include "rf_internal.h"
+#include <new>
 
-struct rf_encoder { int unused; };
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-extern "C" int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config*, const rf_encoder_weights*, int) {
-  if (out) *out = nullptr;
-  rf_set_error("rf_encoder_create: encoder kernels are not part of this build yet");
-  return RF_ERR_UNSUPPORTED;
+#define HID 384
+#define HEAD_DIM 32
+
+struct rf_encoder {
+  rf_encoder_config cfg;
+  rf_encoder_weights w;      // row-major originals (embeddings, biases, LN)
+  int device;
+  const uint4* qkv_t;        // tiled [L][3H/32][H/16][64]
+  const uint4* ao_t;         // tiled [L][H/32][H/16][64]
+  const uint4* ff1_t;        // tiled [L][I/32][H/16][64]
+  const uint4* ff2_t;        // tiled [L][H/32][I/16][64]
+};
+
+static bool cfg_supported(const rf_encoder_config* c) {
+  return c && c->hidden == HID && c->heads > 0 && c->hidden / c->heads == HEAD_DIM &&
+         c->hidden % c->heads == 0 && c->intermediate > 0 && c->intermediate % 384 == 0 &&
+         c->layers > 0 && c->vocab_size > 0 && c->max_position > 0 && c->type_vocab > 0;
 }
-extern "C" int rf_encoder_destroy(rf_encoder_t*) { return RF_OK; }
-extern "C" size_t rf_encode_workspace_bytes(const rf_encoder_t*, int, int) { return 0; }
-extern "C" int rf_encode(const rf_encoder_t*, const int32_t*, const int32_t*, int, int, void*, float*,
-                         void*, size_t, void*) {
-  rf_set_error("rf_encode: encoder kernels are not part of this build yet");
-  return RF_ERR_UNSUPPORTED;
+
+static size_t layer_weight_elems(const rf_encoder_config* c) {
+  return (size_t)3 * HID * HID + (size_t)HID * HID + (size_t)2 * c->intermediate * HID;
+}
+
+extern "C" size_t rf_encoder_storage_bytes(const rf_encoder_config* cfg) {
+  if (!cfg_supported(cfg)) return 0;
+  return (size_t)cfg->layers * layer_weight_elems(cfg) * sizeof(_Float16);
+}
+
+extern "C" int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cfg,
+                                 const rf_encoder_weights* w, void* storage_dev,
+                                 size_t storage_bytes, int device, void* stream) {
+  if (!out || !cfg || !w || !storage_dev) {
+    rf_set_error("rf_encoder_create: null argument");
+    return RF_ERR_INVALID;
+  }
+  *out = nullptr;
+  if (!cfg_supported(cfg)) {
+    rf_set_error("rf_encoder_create: unsupported config (need hidden 384, head_dim 32, "
+                 "intermediate %% 384 == 0); got hidden=%d heads=%d intermediate=%d",
+                 cfg->hidden, cfg->heads, cfg->intermediate);
+    return RF_ERR_UNSUPPORTED;
+  }
+  if (storage_bytes < rf_encoder_storage_bytes(cfg) || ((uintptr_t)storage_dev & 15)) {
+    rf_set_error("rf_encoder_create: storage too small or misaligned");
+    return RF_ERR_CAPACITY;
+  }
+  const void* const* ptrs = (const void* const*)w;
+  for (size_t i = 0; i < sizeof(rf_encoder_weights) / sizeof(void*); ++i)
+    if (!ptrs[i] || ((uintptr_t)ptrs[i] & 15)) {
+      rf_set_error("rf_encoder_create: weight pointer %zu null or not 16-byte aligned", i);
+      return RF_ERR_INVALID;
+    }
+  int rc = rf_device_check(device);
+  if (rc != RF_OK) return rc;
+  rf_encoder* e = new (std::nothrow) rf_encoder();
+  if (!e) {
+    rf_set_error("out of host memory");
+    return RF_ERR_INVALID;
+  }
+  e->cfg = *cfg;
+  e->w = *w;
+  e->device = device;
+  hipStream_t st = (hipStream_t)stream;
+  const int L = cfg->layers, I = cfg->intermediate;
+  _Float16* base = (_Float16*)storage_dev;
+  _Float16* qkv = base;
+  _Float16* ao = qkv + (size_t)L * 3 * HID * HID;
+  _Float16* ff1 = ao + (size_t)L * HID * HID;
+  _Float16* ff2 = ff1 + (size_t)L * I * HID;
+  // [L*out, in] row-major -> tiled; out is a multiple of 32 so layers tile independently
+  rf_launch_tile_rows(w->qkv_w, (uint4*)qkv, 0, (int64_t)L * 3 * HID, HID / 16, st);
+  rf_launch_tile_rows(w->ao_w, (uint4*)ao, 0, (int64_t)L * HID, HID / 16, st);
+  rf_launch_tile_rows(w->ff1_w, (uint4*)ff1, 0, (int64_t)L * I, HID / 16, st);
+  rf_launch_tile_rows(w->ff2_w, (uint4*)ff2, 0, (int64_t)L * HID, I / 16, st);
+  RF_HIP(hipGetLastError());
+  e->qkv_t = (const uint4*)qkv;
+  e->ao_t = (const uint4*)ao;
+  e->ff1_t = (const uint4*)ff1;
+  e->ff2_t = (const uint4*)ff2;
+  *out = e;
+  return RF_OK;
+}
+
+extern "C" int rf_encoder_destroy(rf_encoder_t* enc) {
+  delete enc;
+  return RF_OK;
+}
+
+// ---- workspace ---------------------------------------------------------------------
+struct EncWs {
+  int32_t* tok_off;   // [B + 1]
+  _Float16* x;        // [Mpad, 384]
+  _Float16* y;        // [Mpad, 384]
+  _Float16* qkv;      // [Mpad, 1152]
+  _Float16* ctx;      // [Mpad, 384]
+  _Float16* ff;       // [Mpad, I]
+};
+
+static size_t enc_carve(unsigned char* base, int B, int T, int I, EncWs* ws) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    unsigned char* p = base ? base + off : nullptr;
+    off = (off + bytes + 255) / 256 * 256;
+    return p;
+  };
+  const size_t Mpad = ((size_t)B * T + 63) / 64 * 64;
+  int32_t* tok = (int32_t*)take(((size_t)B + 1) * 4);
+  _Float16* x = (_Float16*)take(Mpad * HID * 2);
+  _Float16* y = (_Float16*)take(Mpad * HID * 2);
+  _Float16* qkv = (_Float16*)take(Mpad * 3 * HID * 2);
+  _Float16* ctx = (_Float16*)take(Mpad * HID * 2);
+  _Float16* ff = (_Float16*)take(Mpad * (size_t)I * 2);
+  if (ws) *ws = EncWs{tok, x, y, qkv, ctx, ff};
+  return off;
+}
+
+extern "C" size_t rf_encode_workspace_bytes(const rf_encoder_t* enc, int B, int T) {
+  if (!enc || B <= 0 || T <= 0) return 0;
+  return enc_carve(nullptr, B, T, enc->cfg.intermediate, nullptr);
+}
+
+// ---- kernels -------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) k_tok_offsets(const int32_t* __restrict__ lens, int B, int T,
+                                                     int32_t* __restrict__ tok_off) {
+  // exclusive scan of clamp(lens, 0, T) by one workgroup
+  __shared__ int32_t part[256];
+  const int tid = threadIdx.x;
+  const int per = (B + 255) / 256;
+  int32_t s = 0;
+  for (int i = 0; i < per; ++i) {
+    const int b = tid * per + i;
+    if (b < B) s += min(max(lens[b], 0), T);
+  }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int32_t run = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int32_t v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    tok_off[B] = run;
+  }
+  __syncthreads();
+  int32_t run = part[tid];
+  for (int i = 0; i < per; ++i) {
+    const int b = tid * per + i;
+    if (b < B) {
+      tok_off[b] = run;
+      run += min(max(lens[b], 0), T);
+    }
+  }
+}
+
+// one wave per (sequence, position) slot; lanes 0..47 each own 8 features
+__global__ void __launch_bounds__(256) k_embed_ln(
+    const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
+    const int32_t* __restrict__ tok_off, int B, int T, int vocab, const _Float16* __restrict__ word,
+    const _Float16* __restrict__ pos, const _Float16* __restrict__ type, const _Float16* __restrict__ g,
+    const _Float16* __restrict__ b, float eps, _Float16* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t slot = wave; slot < (int64_t)B * T; slot += nwaves) {
+    const int bi = (int)(slot / T), p = (int)(slot % T);
+    if (p >= min(max(lens[bi], 0), T)) continue;
+    int id = ids[slot];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    float v[8];
+    if (lane < 48) {
+      const half8 a = *(const half8*)(word + (size_t)id * HID + lane * 8);
+      const half8 c = *(const half8*)(pos + (size_t)p * HID + lane * 8);
+      const half8 d = *(const half8*)(type + lane * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (float)a[j] + (float)c[j] + (float)d[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+    const float mu = wave_sum(s) * (1.f / HID);
+    float q = 0.f;
+    if (lane < 48) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q += (v[j] - mu) * (v[j] - mu);
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / HID) + eps);
+    if (lane < 48) {
+      const half8 gg = *(const half8*)(g + lane * 8);
+      const half8 bb = *(const half8*)(b + lane * 8);
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (_Float16)((v[j] - mu) * rstd * (float)gg[j] + (float)bb[j]);
+      *(half8*)(out + ((size_t)tok_off[bi] + p) * HID + lane * 8) = o;
+    }
+  }
+}
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES_LN = 2 };
+
+// Y[tokens, N] = X[tokens, K] W^T + b with W tiled.  Workgroup = 32 tokens x 384
+// features (grid.y picks the 384-feature group); wave w owns features 96 w .. +96.
+// A operand = weight fragment (contiguous 1 KiB), B operand = 32 token rows, so the
+// accumulator holds TOKEN on the lane and FEATURES in registers: 4 consecutive
+// features per register quad -> 8-byte stores, and a lane-local LayerNorm sum.
+template <int EPI>
+__global__ void __launch_bounds__(256) k_linear(
+    const _Float16* __restrict__ X, int K, const uint4* __restrict__ Wt,
+    const _Float16* __restrict__ bias, _Float16* __restrict__ out, int ldo,
+    const int32_t* __restrict__ m_ptr, const _Float16* __restrict__ res,
+    const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta, float eps) {
+  __shared__ float red[2][4][32];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int t0 = blockIdx.x * 32;
+  const int M = *m_ptr;
+  if (t0 >= M) return;  // whole workgroup: no barrier is skipped by a subset
+  const int KS = K / 16;
+  const int fgroup = blockIdx.y * 384 + wave * 96;  // first feature of this wave
+  const uint4* wbase = Wt + (size_t)(fgroup / 32) * KS * 64 + lane;
+  const _Float16* xrow = X + (size_t)(t0 + c) * K + h * 8;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int fb = 0; fb < 3; ++fb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[fb][i] = 0.f;
+
+  for (int kk = 0; kk < KS; ++kk) {
+    const half8 b = *(const half8*)(xrow + kk * 16);
+#pragma unroll
+    for (int fb = 0; fb < 3; ++fb) {
+      const uint4 av = wbase[((size_t)fb * KS + kk) * 64];
+      acc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, av), b, acc[fb], 0, 0, 0);
+    }
+  }
+
+  const int token = t0 + c;
+  // acc[fb][4 g + j] = Y[token][fgroup + 32 fb + 8 g + 4 h + j]
+  float v[3][16];
+#pragma unroll
+  for (int fb = 0; fb < 3; ++fb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f = fgroup + 32 * fb + 8 * g + 4 * h;
+      const half4 bv = *(const half4*)(bias + f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float y = acc[fb][4 * g + j] + (float)bv[j];
+        if (EPI == EPI_BIAS_GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752f));
+        v[fb][4 * g + j] = y;
+      }
+      if (EPI == EPI_BIAS_RES_LN) {
+        const half4 rv = *(const half4*)(res + (size_t)token * HID + f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[fb][4 * g + j] += (float)rv[j];
+      }
+    }
+
+  float mu = 0.f, rstd = 1.f;
+  if (EPI == EPI_BIAS_RES_LN) {
+    // LayerNorm over the 384 features of a token: 48 per lane, x2 lane halves, x4 waves
+    float s = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < 3; ++fb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += v[fb][i];
+    s += __shfl_xor(s, 32);
+    if (h == 0) red[0][wave][c] = s;
+    __syncthreads();
+    mu = (red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]) * (1.f / HID);
+    float q = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < 3; ++fb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) q += (v[fb][i] - mu) * (v[fb][i] - mu);
+    q += __shfl_xor(q, 32);
+    if (h == 0) red[1][wave][c] = q;
+    __syncthreads();
+    rstd = rsqrtf((red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]) * (1.f / HID) + eps);
+  }
+
+  if (token < M) {
+#pragma unroll
+    for (int fb = 0; fb < 3; ++fb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f = fgroup + 32 * fb + 8 * g + 4 * h;
+        half4 o;
+        if (EPI == EPI_BIAS_RES_LN) {
+          const half4 gv = *(const half4*)(gamma + f);
+          const half4 be = *(const half4*)(beta + f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = (_Float16)((v[fb][4 * g + j] - mu) * rstd * (float)gv[j] + (float)be[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[fb][4 * g + j];
+        }
+        *(half4*)(out + (size_t)token * ldo + f) = o;
+      }
+  }
+}
+
+// softmax(q k^T / sqrt(32)) v for one (sequence, head): K and V rows in LDS, one
+// query per thread, online softmax in fp32.
+__global__ void __launch_bounds__(256) k_attention(const _Float16* __restrict__ qkv,
+                                                   const int32_t* __restrict__ tok_off,
+                                                   _Float16* __restrict__ ctx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int b = blockIdx.x, head = blockIdx.y;
+  const int r0 = tok_off[b];
+  const int n = tok_off[b + 1] - r0;
+  if (n <= 0) return;
+  half8* ks = (half8*)lds;            // [n][4]
+  half8* vs = ks + (size_t)n * 4;     // [n][4]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n * 4; i += 256) {
+    const int row = i >> 2, part = i & 3;
+    const _Float16* src = qkv + (size_t)(r0 + row) * (3 * HID) + head * HEAD_DIM + part * 8;
+    ks[i] = *(const half8*)(src + HID);
+    vs[i] = *(const half8*)(src + 2 * HID);
+  }
+  __syncthreads();
+  const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
+  for (int qi = tid; qi < n; qi += 256) {
+    float q[HEAD_DIM];
+    const _Float16* qsrc = qkv + (size_t)(r0 + qi) * (3 * HID) + head * HEAD_DIM;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const half8 t = *(const half8*)(qsrc + p * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[p * 8 + j] = (float)t[j] * scale;
+    }
+    float m = -INFINITY, l = 0.f;
+    float o[HEAD_DIM];
+#pragma unroll
+    for (int d = 0; d < HEAD_DIM; ++d) o[d] = 0.f;
+    for (int j = 0; j < n; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const half8 kv = ks[j * 4 + p];  // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(q[p * 8 + e], (float)kv[e], s);
+      }
+      const float mn = fmaxf(m, s);
+      const float corr = __expf(m - mn);
+      const float pj = __expf(s - mn);
+      l = l * corr + pj;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const half8 vv = vs[j * 4 + p];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[p * 8 + e] = fmaf(pj, (float)vv[e], o[p * 8 + e] * corr);
+      }
+      m = mn;
+    }
+    const float inv = 1.f / l;
+    _Float16* dst = ctx + (size_t)(r0 + qi) * HID + head * HEAD_DIM;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      half8 t;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (_Float16)(o[p * 8 + e] * inv);
+      *(half8*)(dst + p * 8) = t;
+    }
+  }
+}
+
+// masked mean over the sequence (all packed rows are valid), clamp(count, 1e-9),
+// then x / max(||x||, 1e-12).  One workgroup (192 threads x 2 features) per sequence.
+__global__ void __launch_bounds__(192) k_pool_norm(const _Float16* __restrict__ x,
+                                                   const int32_t* __restrict__ tok_off,
+                                                   _Float16* __restrict__ out16,
+                                                   float* __restrict__ out32) {
+  __shared__ float red[3];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int r0 = tok_off[b];
+  const int n = tok_off[b + 1] - r0;
+  float a0 = 0.f, a1 = 0.f;
+  for (int r = 0; r < n; ++r) {
+    const _Float16* row = x + (size_t)(r0 + r) * HID + tid * 2;
+    a0 += (float)row[0];
+    a1 += (float)row[1];
+  }
+  const float cnt = fmaxf((float)n, 1e-9f);
+  a0 /= cnt;
+  a1 /= cnt;
+  float s = wave_sum(a0 * a0 + a1 * a1);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2]), 1e-12f);
+  a0 /= nrm;
+  a1 /= nrm;
+  if (out16) {
+    out16[(size_t)b * HID + tid * 2] = (_Float16)a0;
+    out16[(size_t)b * HID + tid * 2 + 1] = (_Float16)a1;
+  }
+  if (out32) {
+    out32[(size_t)b * HID + tid * 2] = a0;
+    out32[(size_t)b * HID + tid * 2 + 1] = a1;
+  }
+}
+
+// ---- forward pass -----------------------------------------------------------------------
+template <int EPI>
+static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Float16* bias,
+                          _Float16* out, int N, int tiles, const int32_t* m_ptr, const _Float16* res,
+                          const _Float16* g, const _Float16* b, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(k_linear<EPI>, dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out, N,
+                     m_ptr, res, g, b, eps);
+}
+
+extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev,
+                         int B, int T, void* out_f16_dev, float* out_f32_dev, void* workspace_dev,
+                         size_t workspace_bytes, void* stream) {
+  if (!enc || !ids_dev || !lens_dev || !workspace_dev || (!out_f16_dev && !out_f32_dev)) {
+    rf_set_error("rf_encode: null argument");
+    return RF_ERR_INVALID;
+  }
+  if (B <= 0 || T <= 0 || T > enc->cfg.max_position) {
+    rf_set_error("rf_encode: B=%d T=%d out of range (max_position %d)", B, T, enc->cfg.max_position);
+    return RF_ERR_INVALID;
+  }
+  if ((size_t)T * 2 * HEAD_DIM * 2 > 160 * 1024) {
+    rf_set_error("rf_encode: T=%d does not fit the attention kernel's LDS", T);
+    return RF_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < rf_encode_workspace_bytes(enc, B, T) || ((uintptr_t)workspace_dev & 15)) {
+    rf_set_error("rf_encode: workspace too small or misaligned");
+    return RF_ERR_CAPACITY;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const rf_encoder_config& c = enc->cfg;
+  const rf_encoder_weights& w = enc->w;
+  const int I = c.intermediate, L = c.layers;
+  EncWs ws;
+  enc_carve((unsigned char*)workspace_dev, B, T, I, &ws);
+  const int tiles = (int)(((size_t)B * T + 31) / 32);
+  const int32_t* m_ptr = ws.tok_off + B;
+
+  hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off);
+  {
+    int64_t waves = (int64_t)B * T;
+    int grid = (int)((waves + 3) / 4);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_embed_ln, dim3(grid), dim3(256), 0, st, ids_dev, lens_dev, ws.tok_off, B, T,
+                       c.vocab_size, (const _Float16*)w.word_emb, (const _Float16*)w.pos_emb,
+                       (const _Float16*)w.type_emb, (const _Float16*)w.emb_ln_g,
+                       (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
+  }
+  const size_t attn_lds = (size_t)T * 2 * HEAD_DIM * 2;
+  static size_t attn_attr = 0;
+  if (attn_lds > attn_attr) {
+    RF_HIP(hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)attn_lds));
+    attn_attr = attn_lds;
+  }
+  _Float16* x = ws.x;
+  _Float16* y = ws.y;
+  for (int l = 0; l < L; ++l) {
+    const uint4* qkv_t = enc->qkv_t + (size_t)l * 3 * HID * HID / 8;
+    const uint4* ao_t = enc->ao_t + (size_t)l * HID * HID / 8;
+    const uint4* ff1_t = enc->ff1_t + (size_t)l * I * HID / 8;
+    const uint4* ff2_t = enc->ff2_t + (size_t)l * HID * I / 8;
+    launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
+                            3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, st);
+    hipLaunchKernelGGL(k_attention, dim3(B, c.heads), dim3(256), attn_lds, st, ws.qkv, ws.tok_off,
+                       ws.ctx);
+    launch_linear<EPI_BIAS_RES_LN>(ws.ctx, HID, ao_t, (const _Float16*)w.ao_b + (size_t)l * HID, y, HID,
+                                   tiles, m_ptr, x, (const _Float16*)w.ln1_g + (size_t)l * HID,
+                                   (const _Float16*)w.ln1_b + (size_t)l * HID, c.ln_eps, st);
+    launch_linear<EPI_BIAS_GELU>(y, HID, ff1_t, (const _Float16*)w.ff1_b + (size_t)l * I, ws.ff, I,
+                                 tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, st);
+    launch_linear<EPI_BIAS_RES_LN>(ws.ff, I, ff2_t, (const _Float16*)w.ff2_b + (size_t)l * HID, x, HID,
+                                   tiles, m_ptr, y, (const _Float16*)w.ln2_g + (size_t)l * HID,
+                                   (const _Float16*)w.ln2_b + (size_t)l * HID, c.ln_eps, st);
+  }
+  hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(192), 0, st, x, ws.tok_off, (_Float16*)out_f16_dev,
+                     out_f32_dev);
+  RF_HIP(hipGetLastError());
+  return RF_OK;
 }

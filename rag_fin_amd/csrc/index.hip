@@ -193,6 +193,13 @@ static inline int grid_for(int64_t work_items, int block) {
   return (int)g;
 }
 
+void rf_launch_tile_rows(const void* rows, uint4* tiles, int64_t first_row, int64_t n, int KS,
+                         hipStream_t st) {
+  const int64_t groups = (n + 31) / 32;
+  hipLaunchKernelGGL(k_tile_rows, dim3(grid_for(groups * KS * 2 * 32, 256)), dim3(256), 0, st,
+                     (const uint4*)rows, tiles, first_row, n, KS);
+}
+
 extern "C" int rf_index_reset(rf_index_t* ix, void* stream) {
   if (!ix) {
     rf_set_error("rf_index_reset: null index");
@@ -229,9 +236,7 @@ extern "C" int rf_index_add_f16(rf_index_t* ix, const void* rows_dev, int64_t n,
     hipLaunchKernelGGL(k_zero_u4, dim3(grid_for((int64_t)cnt, 256)), dim3(256), 0, st,
                        ix->tiles + (size_t)first_new_block * KS * 64, cnt);
   }
-  const int64_t groups = (n + 31) / 32;
-  hipLaunchKernelGGL(k_tile_rows, dim3(grid_for(groups * KS * 2 * 32, 256)), dim3(256), 0, st,
-                     (const uint4*)rows_dev, ix->tiles, ix->size, n, KS);
+  rf_launch_tile_rows(rows_dev, ix->tiles, ix->size, n, KS, st);
   hipLaunchKernelGGL(k_max_norm2, dim3(grid_for(n * 64, 256)), dim3(256), 0, st,
                      (const _Float16*)rows_dev, n, ix->dim, ix->max_norm2);
   RF_HIP(hipGetLastError());

@@ -67,6 +67,9 @@ void rf_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// index.hip: row-major fp16 [n, 16*KS] -> fragment-tiled (also used for encoder weights)
+void rf_launch_tile_rows(const void* rows, uint4* tiles, int64_t first_row, int64_t n, int KS,
+                         hipStream_t st);
 // scan.hip
 int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_workspace& ws,
                      int* P_out, hipStream_t st);

@@ -1,0 +1,234 @@
+"""Sentence embedder on the GPU: the in-process replacement for
+`SentenceTransformer('all-MiniLM-L6-v2')` on the vector-RAG path.
+
+Reference call sites mirrored:
+  ctor            vector_rag_mcp/main.py:41, retrieve.py:14, "chunking_storing (1).py":8
+  .encode([q])    vector_rag_mcp/main.py:50, retrieve.py:27  -> np.float32 [1, 384]
+  .encode(texts)  "chunking_storing (1).py":379-380          -> np.float32 [n, 384]
+
+The reference loads the model by NAME (a network fetch); here the checkpoint comes
+from a LOCAL directory in the Hugging Face layout (config.json, vocab.txt,
+model.safetensors), read with safetensors only.  The forward pass runs in
+libragfin_hip.so (rf_encode); there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from ctypes import c_void_p
+
+import numpy as np
+
+from . import _lib
+from .store import require_gpu
+from .tokenizer import WordPieceTokenizer
+
+MINILM_L6 = dict(vocab_size=30522, hidden=384, layers=6, heads=12, intermediate=1536,
+                 max_position=512, type_vocab=2, ln_eps=1e-12)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def stack_hf_state_dict(sd: dict, cfg: dict) -> dict:
+    """Hugging Face BertModel tensor names -> the stacked layout of rf_encoder_weights."""
+    def get(name):
+        for prefix in ("", "bert.", "0.auto_model."):
+            if prefix + name in sd:
+                return np.asarray(sd[prefix + name], dtype=np.float32)
+        raise KeyError(f"checkpoint lacks {name}")
+    L = cfg["layers"]
+    lay = lambda l, n: get(f"encoder.layer.{l}.{n}")
+    return {
+        "word_emb": get("embeddings.word_embeddings.weight"),
+        "pos_emb": get("embeddings.position_embeddings.weight"),
+        "type_emb": get("embeddings.token_type_embeddings.weight"),
+        "emb_ln_g": get("embeddings.LayerNorm.weight"), "emb_ln_b": get("embeddings.LayerNorm.bias"),
+        "qkv_w": np.stack([np.concatenate([lay(l, "attention.self.query.weight"),
+                                           lay(l, "attention.self.key.weight"),
+                                           lay(l, "attention.self.value.weight")]) for l in range(L)]),
+        "qkv_b": np.stack([np.concatenate([lay(l, "attention.self.query.bias"),
+                                           lay(l, "attention.self.key.bias"),
+                                           lay(l, "attention.self.value.bias")]) for l in range(L)]),
+        "ao_w": np.stack([lay(l, "attention.output.dense.weight") for l in range(L)]),
+        "ao_b": np.stack([lay(l, "attention.output.dense.bias") for l in range(L)]),
+        "ln1_g": np.stack([lay(l, "attention.output.LayerNorm.weight") for l in range(L)]),
+        "ln1_b": np.stack([lay(l, "attention.output.LayerNorm.bias") for l in range(L)]),
+        "ff1_w": np.stack([lay(l, "intermediate.dense.weight") for l in range(L)]),
+        "ff1_b": np.stack([lay(l, "intermediate.dense.bias") for l in range(L)]),
+        "ff2_w": np.stack([lay(l, "output.dense.weight") for l in range(L)]),
+        "ff2_b": np.stack([lay(l, "output.dense.bias") for l in range(L)]),
+        "ln2_g": np.stack([lay(l, "output.LayerNorm.weight") for l in range(L)]),
+        "ln2_b": np.stack([lay(l, "output.LayerNorm.bias") for l in range(L)]),
+    }
+
+
+class Embedder:
+    """`encode(list[str]) -> np.float32 [n, 384]`, unit-norm rows."""
+
+    def __init__(self, weights: dict, cfg: dict | None = None, tokenizer: WordPieceTokenizer | None = None,
+                 device=None, max_seq_length: int = 256):
+        torch = _torch()
+        self.cfg = dict(cfg or MINILM_L6)
+        self.device = require_gpu(device)
+        self.lib = _lib.load_library()
+        self.tokenizer = tokenizer
+        self.max_seq_length = min(max_seq_length, self.cfg["max_position"])
+        self.dim = self.cfg["hidden"]
+        c = self.cfg
+        self._cfg_c = _lib.EncoderConfig(c["vocab_size"], c["hidden"], c["layers"], c["heads"],
+                                         c["intermediate"], c["max_position"], c["type_vocab"],
+                                         c["ln_eps"])
+        nbytes = self.lib.rf_encoder_storage_bytes(ctypes.byref(self._cfg_c))
+        if nbytes == 0:
+            raise _lib.RagfinError(-2, f"encoder config not supported by the HIP kernels: {c}")
+        # fp16 device copies of every tensor (kept alive: the library keeps pointers)
+        self._w = {}
+        wc = _lib.EncoderWeights()
+        for name in _lib.ENCODER_WEIGHT_FIELDS:
+            t = torch.as_tensor(np.ascontiguousarray(weights[name])).to(torch.float16)
+            t = t.to(self.device).contiguous()
+            self._w[name] = t
+            setattr(wc, name, t.data_ptr())
+        with torch.cuda.device(self.device):
+            self._storage = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            h = c_void_p()
+            _lib.check(self.lib.rf_encoder_create(ctypes.byref(h), ctypes.byref(self._cfg_c),
+                                                  ctypes.byref(wc), c_void_p(self._storage.data_ptr()),
+                                                  nbytes, self.device.index, _lib.current_stream_ptr()))
+        self.handle = h
+        self._ws = None
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.lib.rf_encoder_destroy(h)
+            self.handle = None
+
+    # -- construction -----------------------------------------------------------------
+    @classmethod
+    def from_local(cls, path: str, device=None, max_seq_length: int | None = None) -> "Embedder":
+        """Load config.json + vocab.txt + model.safetensors from a local directory
+        (e.g. a copy of sentence-transformers/all-MiniLM-L6-v2).  Nothing is downloaded."""
+        from safetensors.numpy import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            hc = json.load(f)
+        cfg = dict(vocab_size=hc["vocab_size"], hidden=hc["hidden_size"], layers=hc["num_hidden_layers"],
+                   heads=hc["num_attention_heads"], intermediate=hc["intermediate_size"],
+                   max_position=hc["max_position_embeddings"], type_vocab=hc.get("type_vocab_size", 2),
+                   ln_eps=hc.get("layer_norm_eps", 1e-12))
+        if hc.get("hidden_act", "gelu") != "gelu":
+            raise _lib.RagfinError(-2, f"activation {hc.get('hidden_act')} is not supported (gelu only)")
+        sd = load_file(os.path.join(path, "model.safetensors"))
+        tok = WordPieceTokenizer.from_vocab_file(os.path.join(path, "vocab.txt"))
+        msl = max_seq_length
+        sbert_cfg = os.path.join(path, "sentence_bert_config.json")
+        if msl is None and os.path.exists(sbert_cfg):
+            with open(sbert_cfg) as f:
+                msl = json.load(f).get("max_seq_length")
+        return cls(stack_hf_state_dict(sd, cfg), cfg, tok, device, msl or 256)
+
+    @classmethod
+    def from_random(cls, cfg: dict | None = None, seed: int = 0, tokenizer=None, device=None,
+                    scale: float = 0.05) -> "Embedder":
+        """Seeded random weights of the named architecture (no checkpoint exists
+        offline): same generator as the test oracle so both sides can be rebuilt
+        from the seed alone."""
+        cfg = dict(cfg or MINILM_L6)
+        rng = np.random.default_rng(seed)
+        H, L, I = cfg["hidden"], cfg["layers"], cfg["intermediate"]
+
+        def mat(*shape, s=scale):
+            return (rng.standard_normal(shape, dtype=np.float32) * s).astype(np.float32)
+        w = {"word_emb": mat(cfg["vocab_size"], H), "pos_emb": mat(cfg["max_position"], H),
+             "type_emb": mat(cfg["type_vocab"], H), "emb_ln_g": 1 + mat(H, s=0.1), "emb_ln_b": mat(H, s=0.1),
+             "qkv_w": mat(L, 3 * H, H), "qkv_b": mat(L, 3 * H, s=0.02), "ao_w": mat(L, H, H),
+             "ao_b": mat(L, H, s=0.02), "ln1_g": 1 + mat(L, H, s=0.1), "ln1_b": mat(L, H, s=0.1),
+             "ff1_w": mat(L, I, H), "ff1_b": mat(L, I, s=0.02), "ff2_w": mat(L, H, I),
+             "ff2_b": mat(L, H, s=0.02), "ln2_g": 1 + mat(L, H, s=0.1), "ln2_b": mat(L, H, s=0.1)}
+        return cls(w, cfg, tokenizer, device)
+
+    # -- forward ------------------------------------------------------------------------
+    def _workspace(self, nbytes: int):
+        torch = _torch()
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def encode_ids(self, ids, lens, out_dtype="float16"):
+        """ids int32 [B, T], lens int32 [B] (tensors or arrays) -> [B, 384] tensor on
+        the device (fp16 by default: exactly what CorpusStore stores)."""
+        torch = _torch()
+        ids = torch.as_tensor(ids, dtype=torch.int32).to(self.device).contiguous()
+        lens = torch.as_tensor(lens, dtype=torch.int32).to(self.device).contiguous()
+        if ids.dim() != 2 or lens.shape != (ids.shape[0],):
+            raise ValueError("encode_ids expects ids [B, T] and lens [B]")
+        B, T = ids.shape
+        if T > self.cfg["max_position"]:
+            raise ValueError(f"T={T} exceeds max_position {self.cfg['max_position']}")
+        want32 = out_dtype in ("float32", np.float32)
+        out16 = None if want32 else torch.empty((B, self.dim), dtype=torch.float16, device=self.device)
+        out32 = torch.empty((B, self.dim), dtype=torch.float32, device=self.device) if want32 else None
+        with torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.rf_encode_workspace_bytes(self.handle, B, T))
+            _lib.check(self.lib.rf_encode(self.handle, c_void_p(ids.data_ptr()), c_void_p(lens.data_ptr()),
+                                          B, T, c_void_p(out16.data_ptr()) if out16 is not None else None,
+                                          c_void_p(out32.data_ptr()) if out32 is not None else None,
+                                          c_void_p(ws.data_ptr()), ws.numel(),
+                                          _lib.current_stream_ptr()))
+        return out32 if want32 else out16
+
+    def encode_to_device(self, sentences, batch_tokens: int = 16384):
+        """Tokenise, bucket by length, encode; returns fp16 [n, 384] on the device in
+        the input order."""
+        torch = _torch()
+        if self.tokenizer is None:
+            raise RuntimeError("Embedder has no tokenizer: construct it with from_local(path) or pass "
+                               "tokenizer=WordPieceTokenizer(vocab)")
+        if isinstance(sentences, str):
+            sentences = [sentences]
+        rows = [self.tokenizer.encode(s, self.max_seq_length) for s in sentences]
+        order = sorted(range(len(rows)), key=lambda i: len(rows[i]))
+        out = torch.empty((len(rows), self.dim), dtype=torch.float16, device=self.device)
+        i = 0
+        while i < len(order):
+            T = len(rows[order[i]])
+            j = i
+            # rows are sorted ascending, so the last row of a bucket sets its width
+            while j < len(order) and (j - i + 1) * len(rows[order[j]]) <= max(batch_tokens, len(rows[order[j]])):
+                T = len(rows[order[j]])
+                j += 1
+            idx = order[i:j]
+            ids = np.full((len(idx), T), self.tokenizer.pad_id, dtype=np.int32)
+            lens = np.empty(len(idx), dtype=np.int32)
+            for r, k in enumerate(idx):
+                ids[r, :len(rows[k])] = rows[k]
+                lens[r] = len(rows[k])
+            out[torch.as_tensor(idx, device=self.device)] = self.encode_ids(ids, lens)
+            i = j
+        return out
+
+    def encode(self, sentences, batch_size: int = 32, **_ignored) -> np.ndarray:
+        """sentence-transformers' signature: numpy float32 [n, 384] (or [384] for a str)."""
+        single = isinstance(sentences, str)
+        emb = self.encode_to_device([sentences] if single else list(sentences))
+        arr = emb.float().cpu().numpy()
+        return arr[0] if single else arr
+
+
+def smoke(device) -> None:
+    """Tiny encoder forward checked against the oracle (called by __graft_entry__.smoke)."""
+    from oracle import encoder as oenc
+    cfg = dict(MINILM_L6, layers=2, vocab_size=1000, max_position=64)
+    w = oenc.random_weights(cfg, 3)
+    emb = Embedder(w, cfg, device=device)
+    rng = np.random.default_rng(0)
+    lens = np.array([17, 5, 32, 1], dtype=np.int32)
+    ids = rng.integers(1, 1000, (4, 32)).astype(np.int32)
+    got = emb.encode_ids(ids, lens).float().cpu().numpy()
+    want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids, lens)
+    err = np.abs(got - want).max()
+    assert err < 5e-3, f"encoder smoke: max abs err {err}"

@@ -1,0 +1,142 @@
+"""BERT WordPiece tokenizer (uncased), host-side Python.
+
+Stands in for the tokenizer SentenceTransformer('all-MiniLM-L6-v2') loads by name
+(vector_rag_mcp/main.py:41); the vocabulary file must be supplied from a local
+path -- nothing is fetched.  Algorithm: BERT "basic" tokenisation (clean, lower,
+strip accents, split punctuation, space CJK) followed by greedy longest-match
+WordPiece with the "##" continuation prefix, wrapped in [CLS] ... [SEP] and
+truncated to max_seq_length (256 for all-MiniLM-L6-v2).
+"""
+from __future__ import annotations
+
+import unicodedata
+from typing import Iterable
+
+
+def _is_whitespace(ch: str) -> bool:
+    return ch in " \t\n\r" or unicodedata.category(ch) == "Zs"
+
+
+def _is_control(ch: str) -> bool:
+    if ch in "\t\n\r":
+        return False
+    return unicodedata.category(ch).startswith("C")
+
+
+def _is_punctuation(ch: str) -> bool:
+    cp = ord(ch)
+    if 33 <= cp <= 47 or 58 <= cp <= 64 or 91 <= cp <= 96 or 123 <= cp <= 126:
+        return True
+    return unicodedata.category(ch).startswith("P")
+
+
+def _is_cjk(cp: int) -> bool:
+    return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF
+            or 0x2A700 <= cp <= 0x2B73F or 0x2B740 <= cp <= 0x2B81F or 0x2B820 <= cp <= 0x2CEAF
+            or 0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
+
+
+class WordPieceTokenizer:
+    def __init__(self, vocab: dict[str, int] | Iterable[str], do_lower_case: bool = True,
+                 unk_token: str = "[UNK]", cls_token: str = "[CLS]", sep_token: str = "[SEP]",
+                 pad_token: str = "[PAD]", max_input_chars_per_word: int = 100):
+        if not isinstance(vocab, dict):
+            vocab = {tok: i for i, tok in enumerate(vocab)}
+        self.vocab = vocab
+        self.do_lower_case = do_lower_case
+        self.unk, self.cls, self.sep, self.pad = unk_token, cls_token, sep_token, pad_token
+        for t in (unk_token, cls_token, sep_token, pad_token):
+            if t not in vocab:
+                raise ValueError(f"vocabulary lacks the special token {t}")
+        self.unk_id, self.cls_id = vocab[unk_token], vocab[cls_token]
+        self.sep_id, self.pad_id = vocab[sep_token], vocab[pad_token]
+        self.special = {unk_token, cls_token, sep_token, pad_token, "[MASK]"}
+        self.max_chars = max_input_chars_per_word
+
+    @classmethod
+    def from_vocab_file(cls, path: str, **kw) -> "WordPieceTokenizer":
+        with open(path, encoding="utf-8") as f:
+            toks = [line.rstrip("\n") for line in f]
+        return cls({t: i for i, t in enumerate(toks)}, **kw)
+
+    # -- basic tokenisation ---------------------------------------------------------
+    def _clean(self, text: str) -> str:
+        out = []
+        for ch in text:
+            cp = ord(ch)
+            if cp == 0 or cp == 0xFFFD or _is_control(ch):
+                continue
+            if _is_cjk(cp):
+                out.append(" " + ch + " ")
+            elif _is_whitespace(ch):
+                out.append(" ")
+            else:
+                out.append(ch)
+        return "".join(out)
+
+    def _split_punct(self, word: str) -> list[str]:
+        pieces, cur = [], []
+        for ch in word:
+            if _is_punctuation(ch):
+                if cur:
+                    pieces.append("".join(cur))
+                    cur = []
+                pieces.append(ch)
+            else:
+                cur.append(ch)
+        if cur:
+            pieces.append("".join(cur))
+        return pieces
+
+    def basic_tokens(self, text: str) -> list[str]:
+        text = unicodedata.normalize("NFC", self._clean(text))
+        out = []
+        for word in text.strip().split():
+            if word in self.special:
+                out.append(word)
+                continue
+            if self.do_lower_case:
+                word = word.lower()
+                word = "".join(c for c in unicodedata.normalize("NFD", word)
+                               if unicodedata.category(c) != "Mn")
+            out.extend(self._split_punct(word))
+        return out
+
+    # -- wordpiece ----------------------------------------------------------------------
+    def wordpiece(self, word: str) -> list[int]:
+        if len(word) > self.max_chars:
+            return [self.unk_id]
+        ids, start = [], 0
+        while start < len(word):
+            end = len(word)
+            cur = None
+            while start < end:
+                sub = word[start:end]
+                if start > 0:
+                    sub = "##" + sub
+                if sub in self.vocab:
+                    cur = self.vocab[sub]
+                    break
+                end -= 1
+            if cur is None:
+                return [self.unk_id]
+            ids.append(cur)
+            start = end
+        return ids
+
+    def encode(self, text: str, max_length: int = 256) -> list[int]:
+        ids = []
+        for w in self.basic_tokens(text):
+            ids.extend(self.wordpiece(w) if w not in self.special else [self.vocab[w]])
+        ids = ids[:max(0, max_length - 2)]
+        return [self.cls_id] + ids + [self.sep_id]
+
+    def batch(self, texts: list[str], max_length: int = 256):
+        """-> (ids int32 [B, T] padded with [PAD], lens int32 [B]), T = longest row."""
+        import numpy as np
+        rows = [self.encode(t, max_length) for t in texts]
+        T = max((len(r) for r in rows), default=1)
+        ids = np.full((len(rows), T), self.pad_id, dtype=np.int32)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = r
+        return ids, np.asarray([len(r) for r in rows], dtype=np.int32)

@@ -1,0 +1,108 @@
+"""`VectorRAG`: the object the reference's MCP server is built around
+(vector_rag_mcp/main.py:36-123; CLI twin `SimpleRAG`, retrieve.py:6-82), with the
+same method names, defaults and return keys, backed by the in-process GPU
+embedder + corpus store instead of sentence-transformers + a Milvus server.
+
+The LLM generation step (Gemini, main.py:40,97) is outside this build's scope: a
+`generator` callable can be plugged in; without one `search_and_answer` returns the
+reference's own failure shape {"error", "contexts", "context_count"}.
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import Callable, Sequence
+
+logger = logging.getLogger(__name__)
+
+OUTPUT_FIELDS = ["text", "period", "chunk_type", "statement_type", "primary_value"]
+
+PROMPT = """Based on the provided financial data about ICICI Bank, answer the question accurately.
+
+QUESTION: {question}
+
+CONTEXT:
+{context}
+
+INSTRUCTIONS:
+- Use exact numbers from the context (include decimals and units)
+- If information is not available, say so clearly
+- Be concise and factual
+- Include the relevant period/quarter
+
+ANSWER:"""
+
+
+class VectorRAG:
+    def __init__(self, gemini_api_key: str | None = None, collection_name: str = "fin_chunks", *,
+                 embedder=None, store=None, generator: Callable[[str], str] | None = None,
+                 llm_delay_s: float = 1.0):
+        """embedder: .encode(list[str]) -> [n, dim] (rag_fin_amd.embedder.Embedder);
+        store: rag_fin_amd.store.CorpusStore.  `gemini_api_key` is accepted for
+        signature compatibility and only handed to `generator` factories upstream."""
+        if embedder is None or store is None:
+            raise ValueError("VectorRAG needs an embedder and a corpus store (see rag_fin_amd.service."
+                             "build_rag); there is no remote Milvus/sentence-transformers fallback")
+        self.similarity_model = embedder
+        self.collection = store
+        self.collection_name = collection_name
+        self.generator = generator
+        self.llm_delay_s = llm_delay_s
+        self.collection.load()
+        logger.info("VectorRAG ready on collection %s (%d chunks)", collection_name,
+                    self.collection.num_entities)
+
+    # -- retrieval ---------------------------------------------------------------------
+    @staticmethod
+    def _contexts(hits) -> list[dict]:
+        return [{"rank": i + 1, "text": h.entity.text, "period": h.entity.period,
+                 "chunk_type": h.entity.chunk_type, "statement_type": h.entity.statement_type,
+                 "primary_value": h.entity.primary_value, "score": float(h.score)}
+                for i, h in enumerate(hits)]
+
+    def search(self, query: str, top_k: int = 3) -> list[dict]:
+        """Ranked context dicts, keys exactly as vector_rag_mcp/main.py:59-70."""
+        q = self.similarity_model.encode([query])
+        results = self.collection.search(q, "embedding", {"metric_type": "COSINE"}, top_k,
+                                         output_fields=OUTPUT_FIELDS)
+        return self._contexts(results[0])
+
+    retrieve = search  # BASELINE.json's "retrieve(query, k)" name for the same call
+
+    def search_batch(self, queries: Sequence[str], top_k: int = 3) -> list[list[dict]]:
+        """Many queries in one embed + one corpus sweep per 64 (new: the reference
+        is strictly one query per call)."""
+        if not queries:
+            return []
+        q = self.similarity_model.encode(list(queries))
+        results = self.collection.search(q, "embedding", {"metric_type": "COSINE"}, top_k,
+                                         output_fields=OUTPUT_FIELDS)
+        return [self._contexts(r) for r in results]
+
+    # -- generation (out of scope; interface kept) -----------------------------------------
+    def build_prompt(self, question: str, contexts: list[dict]) -> str:
+        ctx = "\n\n".join(f"Context {i + 1} [{c['period']} - {c['chunk_type']}]:\n{c['text']}"
+                          for i, c in enumerate(contexts))
+        return PROMPT.format(question=question, context=ctx)
+
+    def search_and_answer(self, question: str, top_k: int = 3) -> dict:
+        contexts = self.search(question, top_k)
+        prompt = self.build_prompt(question, contexts)
+        try:
+            if self.generator is None:
+                raise RuntimeError("no LLM generator configured (generation is outside this build)")
+            if self.llm_delay_s:
+                time.sleep(self.llm_delay_s)
+            answer = self.generator(prompt)
+            return {"answer": str(answer).strip(), "contexts": contexts, "context_count": len(contexts)}
+        except Exception as e:  # the reference's blanket handler (main.py:103-108)
+            return {"error": str(e), "contexts": contexts, "context_count": len(contexts)}
+
+    def health_check(self) -> dict:
+        try:
+            n = self.collection.num_entities
+            llm = "available" if self.generator is not None else "not configured"
+            return {"status": "healthy", "milvus": "in-process MI355X store", "gemini": llm,
+                    "collection": self.collection_name, "total_chunks": n}
+        except Exception as e:
+            return {"status": "unhealthy", "error": str(e)}

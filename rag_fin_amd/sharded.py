@@ -77,8 +77,10 @@ class ShardedSearcher:
         B = exact.shape[0]
         # one collective: pack {score bits, id} as int64 [B, 2k]
         packed = torch.cat([exact.view(torch.int64), ids], dim=1).contiguous()
-        gathered = torch.empty((self.world, B, 2 * k), dtype=torch.int64, device=packed.device)
-        self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
+        # concatenated-along-dim-0 output: the form both RCCL and gloo accept
+        flat = torch.empty((self.world * B, 2 * k), dtype=torch.int64, device=packed.device)
+        self.dist.all_gather_into_tensor(flat, packed, group=self.group)
+        gathered = flat.view(self.world, B, 2 * k)
         exact_all = gathered[:, :, :k].contiguous().view(torch.float64)
         ids_all = gathered[:, :, k:].contiguous()
         scores, gids = self.backend.merge(exact_all, ids_all, k)

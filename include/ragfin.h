@@ -114,6 +114,9 @@ int rf_search_exhaustive(const rf_index_t* ix, const void* q_dev, int B, int k,
  * reference is single-process); see SURVEY.md 8e. */
 int rf_merge_shards(const double* exact_dev, const int64_t* ids_dev, int W, int B, int k,
                     float* scores_out_dev, int64_t* ids_out_dev, void* stream);
+/* Tuning hook (experiments / A-B runs in one process): key in {"ring24",
+ * "emit_wgs_per_cu", "sample_bpw"}.  No reference counterpart. */
+int rf_set_tuning(const char* key, int value);
 /* Test hook: raw MFMA scan scores fp32 [B, n] for the first n rows. */
 int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,
                     float* out_dev, void* stream);

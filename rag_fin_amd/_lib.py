@@ -64,6 +64,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_size_t, c_void_p]),
     "rf_merge_shards": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p]),
+    "rf_set_tuning": (c_int, [c_char_p, c_int]),
     "rf_debug_scores": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "rf_encoder_storage_bytes": (c_size_t, [POINTER(EncoderConfig)]),
     "rf_encoder_create": (c_int, [POINTER(c_void_p), POINTER(EncoderConfig),
@@ -78,7 +79,8 @@ _lib = None
 
 
 def library_path() -> str:
-    return _build.LIB_PATH
+    # RAGFIN_LIB: load an alternative build of the same ABI (tuning experiments)
+    return os.environ.get("RAGFIN_LIB") or _build.LIB_PATH
 
 
 def load_library() -> ctypes.CDLL:

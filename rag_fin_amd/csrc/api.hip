@@ -2,6 +2,7 @@
 // Reference call site replaced: Collection.search(query_embedding, "embedding",
 // {"metric_type": "COSINE"}, top_k, ...) -- vector_rag_mcp/main.py:51-57.
 #include "rf_internal.h"
+#include <stdlib.h>
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -15,6 +16,9 @@ static size_t carve(unsigned char* base, rf_workspace* ws) {
   float* thr = (float*)take(RF_QCHUNK * sizeof(float));
   float* eps = (float*)take(RF_QCHUNK * sizeof(float));
   uint32_t* cnt = (uint32_t*)take((size_t)RF_QCHUNK * RF_CAND_SHARDS * sizeof(uint32_t));
+  uint32_t* gmax = (uint32_t*)take((size_t)RF_QCHUNK * RF_MAX_K * sizeof(uint32_t));
+  uint32_t* bar = (uint32_t*)take(16 * sizeof(uint32_t));
+  const size_t ctl_bytes = off;
   float* pmax = (float*)take((size_t)RF_QCHUNK * RF_SAMPLE_WGS * sizeof(float));
   uint2* cand = (uint2*)take((size_t)RF_QCHUNK * RF_CAND_SHARDS * RF_SHARD_CAP * sizeof(uint2));
   double* exs = (double*)take((size_t)RF_QCHUNK * RF_EX_WGS * RF_MAX_K * sizeof(double));
@@ -23,6 +27,9 @@ static size_t carve(unsigned char* base, rf_workspace* ws) {
     ws->thr = thr;
     ws->eps = eps;
     ws->cand_cnt = cnt;
+    ws->gmax = gmax;
+    ws->bar = bar;
+    ws->ctl_bytes = ctl_bytes;
     ws->pmax = pmax;
     ws->cand = cand;
     ws->ex_score = exs;
@@ -65,6 +72,31 @@ static int check_search_args(const char* fn, const rf_index_t* ix, const void* q
 static void fill_empty(int B, int k, float* scores, int64_t* ids, double* exact, uint32_t* flags,
                        hipStream_t st);
 
+// Scan pipeline: three kernels (sample -> threshold -> emit; the default) or the
+// single-launch fused scan (RF_FUSED=1 / rf_set_tuning("fused", 1)).  On MI355X the
+// fused form measured SLOWER: its in-kernel hand-off costs 3-4 dependent global
+// round trips of ~8 us each under the saturating stream.
+int rf_tuning_fused = -1;
+static bool use_fused() {
+  if (rf_tuning_fused < 0) {
+    const char* v = getenv("RF_FUSED");
+    rf_tuning_fused = (v && v[0] == '1') ? 1 : 0;
+  }
+  return rf_tuning_fused != 0;
+}
+
+// The control block (counters, group maxima, hand-off words) must be zero when a
+// search starts.  k_merge leaves it zero for the next call; a workspace this index
+// has not used before is zeroed here once.
+static int prepare_workspace(const rf_index* ix, const void* base, const rf_workspace& ws,
+                             hipStream_t st) {
+  if (ix->ws_clean != base) {
+    RF_HIP(hipMemsetAsync((void*)base, 0, ws.ctl_bytes, st));
+    ix->ws_clean = base;
+  }
+  return RF_OK;
+}
+
 __global__ void k_fill_empty(int n, int B, float* scores, int64_t* ids, double* exact,
                              uint32_t* flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,20 +130,27 @@ extern "C" int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, 
   }
   rf_workspace ws;
   carve((unsigned char*)workspace_dev, &ws);
+  rc = prepare_workspace(ix, workspace_dev, ws, st);
+  if (rc != RF_OK) return rc;
   const int dim = ix->dim;
   for (int q0 = 0; q0 < B; q0 += RF_QCHUNK) {
     const int nb = (B - q0) < RF_QCHUNK ? (B - q0) : RF_QCHUNK;
     const int JB = nb <= 32 ? 1 : 2;
     const _Float16* qc = (const _Float16*)q_dev + (size_t)q0 * dim;
-    int P = 0;
-    if (ix->size > RF_SMALL_ROWS) {
-      rc = rf_launch_sample(ix, qc, nb, JB, ws, &P, st);
+    if (use_fused()) {
+      rc = rf_launch_fused(ix, qc, nb, JB, k, ws, st);
+      if (rc != RF_OK) return rc;
+    } else {
+      int P = 0;
+      if (ix->size > RF_SMALL_ROWS) {
+        rc = rf_launch_sample(ix, qc, nb, JB, ws, &P, st);
+        if (rc != RF_OK) return rc;
+      }
+      rc = rf_launch_threshold(ix, qc, nb, k, P, ws, st);
+      if (rc != RF_OK) return rc;
+      rc = rf_launch_emit(ix, qc, nb, JB, ws, st);
       if (rc != RF_OK) return rc;
     }
-    rc = rf_launch_threshold(ix, qc, nb, k, P, ws, st);
-    if (rc != RF_OK) return rc;
-    rc = rf_launch_emit(ix, qc, nb, JB, ws, st);
-    if (rc != RF_OK) return rc;
     rc = rf_launch_merge(ix, qc, nb, k, id_base, ws, scores_dev + (size_t)q0 * k,
                          ids_dev + (size_t)q0 * k, exact_dev ? exact_dev + (size_t)q0 * k : nullptr,
                          flags_dev ? flags_dev + q0 : nullptr, st);
@@ -139,12 +178,15 @@ extern "C" int rf_search_profile(const rf_index_t* ix, const void* q_dev, int B,
   const int nb = B < RF_QCHUNK ? B : RF_QCHUNK;
   const int JB = nb <= 32 ? 1 : 2;
   int P = 0;
+  rc = prepare_workspace(ix, workspace_dev, ws, st);
   RF_HIP(hipEventRecord(ev[0], st));
-  if (ix->size > RF_SMALL_ROWS) rc = rf_launch_sample(ix, q_dev, nb, JB, ws, &P, st);
+  if (rc == RF_OK && !use_fused() && ix->size > RF_SMALL_ROWS)
+    rc = rf_launch_sample(ix, q_dev, nb, JB, ws, &P, st);
   RF_HIP(hipEventRecord(ev[1], st));
-  if (rc == RF_OK) rc = rf_launch_threshold(ix, q_dev, nb, k, P, ws, st);
+  if (rc == RF_OK && !use_fused()) rc = rf_launch_threshold(ix, q_dev, nb, k, P, ws, st);
   RF_HIP(hipEventRecord(ev[2], st));
-  if (rc == RF_OK) rc = rf_launch_emit(ix, q_dev, nb, JB, ws, st);
+  if (rc == RF_OK)
+    rc = use_fused() ? rf_launch_fused(ix, q_dev, nb, JB, k, ws, st) : rf_launch_emit(ix, q_dev, nb, JB, ws, st);
   RF_HIP(hipEventRecord(ev[3], st));
   if (rc == RF_OK)
     rc = rf_launch_merge(ix, q_dev, nb, k, id_base, ws, scores_dev, ids_dev, exact_dev, flags_dev, st);

@@ -86,6 +86,12 @@ extern "C" int rf_index_create(rf_index_t** out, int dim, int64_t capacity_rows,
   ix->tiles = (uint4*)storage_dev;
   ix->storage_bytes = storage_bytes;
   ix->max_norm2 = (uint32_t*)((char*)storage_dev + (need - 256));
+  {
+    hipDeviceProp_t prop;
+    RF_HIP(hipGetDeviceProperties(&prop, device));
+    ix->num_cus = prop.multiProcessorCount;
+  }
+  ix->ws_clean = nullptr;
   *out = ix;
   return RF_OK;
 }

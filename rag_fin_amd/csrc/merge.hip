@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
     const _Float16* __restrict__ q, int dim, int KS, const uint4* __restrict__ tiles, int k,
     int64_t id_base, const uint32_t* __restrict__ cand_cnt, const uint2* __restrict__ cand,
     uint32_t cap, const float* __restrict__ eps_in, float* __restrict__ scores,
-    int64_t* __restrict__ ids, double* __restrict__ exact, uint32_t* __restrict__ flags) {
+    int64_t* __restrict__ ids, double* __restrict__ exact, uint32_t* __restrict__ flags,
+    uint32_t* __restrict__ cand_cnt_rw, uint32_t* __restrict__ gmax, uint32_t* __restrict__ bar) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned long long* skeys = (unsigned long long*)lds;                       // [1024]
   unsigned long long* wtop = skeys + MERGE_RANK_MAX;                          // [4][RF_MAX_K]
@@ -369,6 +370,11 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
     if (exact) exact[o] = -INFINITY;
   }
   if (tid == 0 && flags) flags[qi] = fl;
+  // leave the control block zero for the next search on this workspace (every
+  // thread of this workgroup read its counters before the barriers above)
+  if (tid < RF_CAND_SHARDS) cand_cnt_rw[qi * RF_CAND_SHARDS + tid] = 0u;
+  if (tid < RF_MAX_K) gmax[qi * RF_MAX_K + tid] = 0u;
+  if (qi == 0 && tid < 2) bar[tid] = 0u;
 }
 // ---- exhaustive exact path ----------------------------------------------------------
 // Workgroup-level running top-k list (sorted, in LDS) updated 256 entries at a
@@ -537,7 +543,7 @@ int rf_launch_merge(const rf_index* ix, const void* q, int B, int k, int64_t id_
   }
   hipLaunchKernelGGL(k_merge, dim3(B), dim3(MERGE_THREADS), lds, st, (const _Float16*)q, ix->dim,
                      ix->KS, ix->tiles, k, id_base, ws.cand_cnt, ws.cand, (uint32_t)RF_SHARD_CAP,
-                     ws.eps, scores, ids, exact, flags);
+                     ws.eps, scores, ids, exact, flags, ws.cand_cnt, ws.gmax, ws.bar);
   RF_HIP(hipGetLastError());
   return RF_OK;
 }

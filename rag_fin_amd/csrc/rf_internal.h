@@ -30,6 +30,8 @@ struct rf_index {
   uint4* tiles;        // device: capacity_blocks * KS * 64 uint4
   uint32_t* max_norm2; // device: bits of max squared row norm (float >= 0)
   size_t storage_bytes;
+  int num_cus;         // compute units of `device` (sizes the co-resident fused grid)
+  mutable const void* ws_clean;  // workspace whose control block this index has zeroed
 };
 
 // per-query candidate capacity of the fused scan: RF_CAND_SHARDS lists (picked by
@@ -49,6 +51,9 @@ struct rf_workspace {
   float* eps;          // [64]
   uint32_t* cand_cnt;  // [64][RF_CAND_SHARDS]
   float* pmax;         // [64][RF_SAMPLE_WGS]
+  uint32_t* gmax;      // [64][RF_MAX_K] fused scan: ordered-uint group maxima (zero = empty)
+  uint32_t* bar;       // [16] fused scan: [0] arrivals, [1] give-up marker
+  size_t ctl_bytes;    // bytes from the workspace base that must be zero before a search
   uint2* cand;         // [64][RF_CAND_SHARDS][RF_SHARD_CAP]  {row, score bits}
   // exhaustive path
   double* ex_score;    // [RF_EX_LISTS][RF_MAX_K]
@@ -78,6 +83,9 @@ int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_wo
 int rf_launch_debug_scores(const rf_index* ix, const void* q, int B, int64_t n, float* out,
                            hipStream_t st);
 int rf_scan_supported_dim(int dim);
+// scan_fused.hip
+int rf_launch_fused(const rf_index* ix, const void* q, int B, int JB, int k, const rf_workspace& ws,
+                    hipStream_t st);
 // merge.hip
 int rf_launch_threshold(const rf_index* ix, const void* q, int B, int k, int P,
                         const rf_workspace& ws, hipStream_t st);

@@ -25,109 +25,16 @@
 //                flushed with one global atomic per entry).
 #include "rf_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#include "scan_common.h"
 
-enum { MODE_SAMPLE = 0, MODE_EMIT = 1 };
-
-#define SCAP 64  // per-wave LDS staging entries (>= 64: one ballot round can add 64)
-
-struct ScanParams {
-  const uint4* corpus;   // tiled
-  const _Float16* q;     // row-major [B, dim]
-  int B;
-  uint32_t n_rows;
-  uint32_t n_work;       // work items (blocks) for this launch
-  uint32_t bstride;      // corpus block index = work index * bstride
-  const float* thr;      // [64]
-  uint32_t* cand_cnt;    // [64][RF_CAND_SHARDS]
-  uint2* cand;           // [64][RF_CAND_SHARDS][cap]
-  uint32_t cap;
-  float* pmax;           // [64][P]
-  int P;
-};
-
-template <int KS>
-struct RingOf {
-  static constexpr int R = (KS <= 24) ? KS : 16;  // must divide KS
-};
-
-__device__ __forceinline__ u32x4 ld_frag(const uint4* p) {
-  return __builtin_nontemporal_load((const u32x4*)p);
-}
-
-__device__ __forceinline__ float max16(const f32x16& a) {
-  float m0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-  float m1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
-  float m2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
-  float m3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
-  return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-}
-
-// row of accumulator register i within the 32-row block (lane half h)
-__device__ __forceinline__ uint32_t acc_row(int i, int h) {
-  return (uint32_t)((i & 3) + 8 * (i >> 2) + 4 * h);
-}
-
-struct EmitState {
-  uint32_t* s_row;     // [SCAP] per wave (LDS)
-  float* s_score;      // [SCAP]
-  uint32_t* s_q;       // [SCAP]
-  uint32_t cnt;        // wave-uniform
-};
-
-__device__ __forceinline__ void emit_flush(EmitState& es, const ScanParams& p, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  for (uint32_t i = lane; i < es.cnt; i += 64) {
-    const uint32_t q = es.s_q[i];
-    // RF_CAND_SHARDS counters per query: same-address atomics serialise (~12 ns
-    // each), and most waves flush together at the end of the scan
-    const uint32_t list = q * RF_CAND_SHARDS + (blockIdx.x & (RF_CAND_SHARDS - 1));
-    const uint32_t slot = atomicAdd(&p.cand_cnt[list], 1u);
-    if (slot < p.cap)
-      p.cand[(size_t)list * p.cap + slot] =
-          make_uint2(es.s_row[i], __builtin_bit_cast(uint32_t, es.s_score[i]));
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  es.cnt = 0;
-}
-
-template <int JB>
-__device__ __forceinline__ void emit_slow(const f32x16 (&acc)[JB], const float (&th)[JB],
-                                       uint32_t row0, int lane, EmitState& es,
-                                       const ScanParams& p) {
-  const int h = lane >> 5;
-#pragma unroll
-  for (int jb = 0; jb < JB; ++jb) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float s = acc[jb][i];
-      const uint32_t row = row0 + acc_row(i, h);
-      const bool pass = (s >= th[jb]) && (row < p.n_rows);
-      const unsigned long long mask = __ballot(pass);
-      if (mask != 0ull) {
-        const uint32_t n = (uint32_t)__popcll(mask);
-        if (es.cnt + n > SCAP) emit_flush(es, p, lane);
-        if (pass) {
-          const uint32_t slot = es.cnt + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-          es.s_row[slot] = row;
-          es.s_score[slot] = s;
-          es.s_q[slot] = (uint32_t)(jb * 32 + (lane & 31));
-        }
-        es.cnt += n;
-      }
-    }
-  }
-}
-
-template <int KS, int JB, int MODE, bool LAST>
-__device__ __forceinline__ void block_step(u32x4 (&ring)[RingOf<KS>::R], const uint4* cur,
+template <int KS, int R, int JB, int MODE, bool LAST>
+__device__ __forceinline__ void block_step(u32x4 (&ring)[R], const uint4* cur,
                                            const uint4* nxt, const u32x4* smemQ, int lane,
                                            uint32_t row0, float (&th)[JB], float (&pm)[JB],
                                            EmitState& es, const ScanParams& p) {
-  constexpr int R = RingOf<KS>::R;
+  static_assert(KS % R == 0, "ring must divide the block");
   // keep the query-fragment LDS reads inside the block: hoisted out of the
   // block loop they would pin JB*KS*4 registers and spill
   asm volatile("" ::: "memory");
@@ -172,9 +79,8 @@ __device__ __forceinline__ void block_step(u32x4 (&ring)[RingOf<KS>::R], const u
   }
 }
 
-template <int KS, int JB, int WAVES, int MODE>
+template <int KS, int R, int JB, int WAVES, int MODE>
 __global__ void __launch_bounds__(WAVES * 64, 2) k_scan(ScanParams p) {
-  constexpr int R = RingOf<KS>::R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* smemQ = (u32x4*)smem_raw;                                   // JB*KS*64 uint4
   unsigned char* tail = smem_raw + (size_t)JB * KS * RF_FRAG_BYTES;  // per-mode scratch
@@ -232,12 +138,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_scan(ScanParams p) {
       const uint32_t b = w * p.bstride;
       const uint4* cur = p.corpus + (size_t)b * (KS * 64) + lane;
       const uint4* nxt = p.corpus + (size_t)(b + W * p.bstride) * (KS * 64) + lane;
-      block_step<KS, JB, MODE, false>(ring, cur, nxt, smemQ, lane, b * 32u, th, pm, es, p);
+      block_step<KS, R, JB, MODE, false>(ring, cur, nxt, smemQ, lane, b * 32u, th, pm, es, p);
     }
     {
       const uint32_t b = w * p.bstride;
       const uint4* cur = p.corpus + (size_t)b * (KS * 64) + lane;
-      block_step<KS, JB, MODE, true>(ring, cur, cur, smemQ, lane, b * 32u, th, pm, es, p);
+      block_step<KS, R, JB, MODE, true>(ring, cur, cur, smemQ, lane, b * 32u, th, pm, es, p);
     }
   }
 
@@ -287,12 +193,12 @@ __global__ void __launch_bounds__(64) k_debug_scores(const uint4* corpus, const 
 }
 
 // ---- host side ----------------------------------------------------------------
-template <int KS, int JB, int WAVES, int MODE>
+template <int KS, int R, int JB, int WAVES, int MODE>
 static int launch_scan(const ScanParams& p, int grid, hipStream_t st) {
   size_t lds = (size_t)JB * KS * RF_FRAG_BYTES;
   if (MODE == MODE_EMIT) lds += (size_t)3 * WAVES * SCAP * 4;
   else lds += (size_t)WAVES * 2 * JB * 32 * 4;
-  auto kern = k_scan<KS, JB, WAVES, MODE>;
+  auto kern = k_scan<KS, R, JB, WAVES, MODE>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     RF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -304,21 +210,72 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t st) {
   return RF_OK;
 }
 
+// ---- tuning knobs (rf_set_tuning / environment at first use) ---------------------------
+extern int rf_tuning_fused;  // api.hip
+struct ScanTuning {
+  int ring24;           // register-ring depth (fragments) of the dim-384 kernels: 6 | 8 | 12 | 24
+  int emit_wgs_per_cu;  // emit grid = CUs x this (0 = default for the dim)
+  int sample_bpw;       // sample blocks per wave
+};
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+static ScanTuning& tuning() {
+  static ScanTuning t = {env_int("RF_RING24", 8), env_int("RF_EMIT_WGS_PER_CU", 0),
+                         env_int("RF_SAMPLE_BPW", 2)};
+  return t;
+}
+extern "C" int rf_set_tuning(const char* key, int value) {
+  ScanTuning& t = tuning();
+  if (!key) return RF_ERR_INVALID;
+  if (!strcmp(key, "ring24") && (value == 6 || value == 8 || value == 12 || value == 24)) t.ring24 = value;
+  else if (!strcmp(key, "emit_wgs_per_cu") && value >= 0 && value <= 4) t.emit_wgs_per_cu = value;
+  else if (!strcmp(key, "sample_bpw") && value >= 1 && value <= 8) t.sample_bpw = value;
+  else if (!strcmp(key, "fused") && (value == 0 || value == 1)) rf_tuning_fused = value;
+  else {
+    rf_set_error("rf_set_tuning: unknown key or bad value (%s = %d)", key, value);
+    return RF_ERR_INVALID;
+  }
+  return RF_OK;
+}
+
 template <int MODE>
 static int dispatch_scan(int KS, int JB, const ScanParams& p, int grid4, int grid8,
                          hipStream_t st) {
-#define RF_CASE(ks, waves, grid)                                              \
-  case ks:                                                                    \
-    return JB == 1 ? launch_scan<ks, 1, waves, MODE>(p, grid, st)             \
-                   : launch_scan<ks, 2, waves, MODE>(p, grid, st);
+#define RF_CASE(ks, r, waves, grid)                                              \
+  case ks:                                                                       \
+    return JB == 1 ? launch_scan<ks, r, 1, waves, MODE>(p, grid, st)             \
+                   : launch_scan<ks, r, 2, waves, MODE>(p, grid, st);
+  // dim 384: the emit sweep runs best with a SHALLOW ring (8 fragments = 8 KiB per
+  // wave in flight: 119 us vs 124 us at 24 -- deeper queues only add latency once
+  // HBM is saturated), the short sample pass with the full-block ring (16 vs 21 us:
+  // it has two blocks per wave and must prefetch the second during the first).
+  if (KS == 24 && MODE == MODE_EMIT) {
+    switch (tuning().ring24) {
+      case 6:
+        return JB == 1 ? launch_scan<24, 6, 1, 4, MODE>(p, grid4, st) : launch_scan<24, 6, 2, 4, MODE>(p, grid4, st);
+      case 8:
+        return JB == 1 ? launch_scan<24, 8, 1, 4, MODE>(p, grid4, st) : launch_scan<24, 8, 2, 4, MODE>(p, grid4, st);
+      case 12:
+        return JB == 1 ? launch_scan<24, 12, 1, 4, MODE>(p, grid4, st) : launch_scan<24, 12, 2, 4, MODE>(p, grid4, st);
+      default:
+        break;
+    }
+#undef RF_CASE
+#define RF_CASE(ks, r, waves, grid)                                              \
+  case ks:                                                                       \
+    return JB == 1 ? launch_scan<ks, r, 1, waves, MODE>(p, grid, st)             \
+                   : launch_scan<ks, r, 2, waves, MODE>(p, grid, st);
+  }
   switch (KS) {
-    RF_CASE(4, 4, grid4)
-    RF_CASE(8, 4, grid4)
-    RF_CASE(16, 4, grid4)
-    RF_CASE(24, 4, grid4)
-    RF_CASE(32, 4, grid4)
-    RF_CASE(48, 8, grid8)
-    RF_CASE(64, 8, grid8)
+    RF_CASE(4, 4, 4, grid4)
+    RF_CASE(8, 8, 4, grid4)
+    RF_CASE(16, 16, 4, grid4)
+    RF_CASE(24, 24, 4, grid4)
+    RF_CASE(32, 16, 4, grid4)
+    RF_CASE(48, 16, 8, grid8)
+    RF_CASE(64, 16, 8, grid8)
     default:
       break;
   }
@@ -337,11 +294,6 @@ int rf_scan_supported_dim(int dim) {
 }
 
 static inline int waves_per_wg(int KS) { return KS >= 48 ? 8 : 4; }
-// tuning knobs (environment, read once): RF_SAMPLE_BPW, RF_EMIT_WGS_PER_CU
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 static inline int wgs_per_cu(int KS) { return KS >= 48 ? 1 : 2; }
 
 int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_workspace& ws,
@@ -350,7 +302,7 @@ int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_
   const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
   const int WAVES = waves_per_wg(KS);
   // one workgroup per CU, SAMPLE_BPW blocks per wave, spread evenly over the corpus
-  static const int SAMPLE_BPW = env_int("RF_SAMPLE_BPW", 2);
+  const int SAMPLE_BPW = tuning().sample_bpw;
   int grid = RF_SAMPLE_WGS;
   if ((uint32_t)grid * WAVES > nblk) grid = (int)(nblk / WAVES);
   if (grid < 1) grid = 1;
@@ -375,7 +327,7 @@ int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_wo
   const int KS = ix->KS;
   const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
   const int WAVES = waves_per_wg(KS);
-  static const int wgs_env = env_int("RF_EMIT_WGS_PER_CU", 0);
+  const int wgs_env = tuning().emit_wgs_per_cu;
   int grid = 256 * (wgs_env > 0 ? wgs_env : wgs_per_cu(KS));
   const uint32_t need = (nblk + WAVES - 1) / WAVES;
   if ((uint32_t)grid > need) grid = (int)need;

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Config 4 of BASELINE.json: on-GPU encode of 10k finance-chunk-sized sequences
+(token ids ~U[40,250], seeded; real tokenizer/vocab are not available offline) with
+the MiniLM-L6 architecture on seeded random weights, then top-10 search over the
+10k corpus.  Reports tokens/s, encoder TFLOP/s (oracle.encoder.flops_per_token) and
+the per-kernel split (HIP events around whole calls; use rocprofv3 for kernels)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chunks", type=int, default=10_000)
+    ap.add_argument("--batch-tokens", type=int, default=32768)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--fixed-len", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+    from oracle import encoder as oenc
+    from rag_fin_amd.embedder import Embedder
+    from rag_fin_amd.store import GpuIndex
+    dev = torch.device("cuda:0")
+    cfg = dict(oenc.MINILM_L6)
+    emb = Embedder(oenc.random_weights(cfg, 0), cfg, device=dev)
+    rng = np.random.default_rng(7)
+    lens = (np.full(args.chunks, args.fixed_len) if args.fixed_len
+            else rng.integers(40, 251, args.chunks)).astype(np.int32)
+    order = np.argsort(lens, kind="stable")
+    batches = []
+    i = 0
+    while i < len(order):
+        j = i
+        while j < len(order) and (j - i + 1) * lens[order[j]] <= args.batch_tokens:
+            j += 1
+        j = max(j, i + 1)
+        idx = order[i:j]
+        T = int(lens[idx].max())
+        ids = rng.integers(1000, cfg["vocab_size"], (len(idx), T)).astype(np.int32)
+        batches.append((torch.from_numpy(ids).to(dev), torch.from_numpy(lens[idx]).to(dev), idx))
+        i = j
+    tokens = int(lens.sum())
+    flops = float(sum(oenc.flops_per_token(cfg, int(l)) * int(l) for l in lens))
+    out = torch.empty((args.chunks, 384), dtype=torch.float16, device=dev)
+
+    def run():
+        for ids, ln, idx in batches:
+            out[torch.as_tensor(idx, device=dev)] = emb.encode_ids(ids, ln)
+    run()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(args.iters):
+        t = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t)
+    best = min(times)
+    ix = GpuIndex(384, args.chunks, dev)
+    ix.add(out)
+    q = out[:64].contiguous()
+    ix.search_raw(q, 10)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(50):
+        ix.search_raw(q, 10)
+    torch.cuda.synchronize()
+    search_ms = (time.perf_counter() - t) / 50 * 1e3
+    print(json.dumps({"workload": f"encode {args.chunks} chunks (lens U[40,250]) + top-10 search, MiniLM-L6 random weights",
+                      "chunks": args.chunks, "tokens": tokens, "batches": len(batches),
+                      "encode_s": round(best, 4), "tokens_per_s": round(tokens / best, 1),
+                      "chunks_per_s": round(args.chunks / best, 1),
+                      "encoder_TFLOPs": round(flops / best / 1e12, 2),
+                      "mfma_f16_peak_TFLOPs": 2500, "frac_of_mfma_peak": round(flops / best / 2.5e15, 4),
+                      "search_batch64_ms": round(search_ms, 4)}))
+
+
+if __name__ == "__main__":
+    main()

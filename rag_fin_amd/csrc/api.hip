@@ -90,10 +90,11 @@ static bool use_fused() {
 // has not used before is zeroed here once.
 static int prepare_workspace(const rf_index* ix, const void* base, const rf_workspace& ws,
                              hipStream_t st) {
-  if (ix->ws_clean != base) {
-    RF_HIP(hipMemsetAsync((void*)base, 0, ws.ctl_bytes, st));
-    ix->ws_clean = base;
-  }
+  for (int i = 0; i < 8; ++i)
+    if (ix->ws_clean[i] == base) return RF_OK;
+  RF_HIP(hipMemsetAsync((void*)base, 0, ws.ctl_bytes, st));
+  ix->ws_clean[ix->ws_clean_next] = base;
+  ix->ws_clean_next = (ix->ws_clean_next + 1) & 7;
   return RF_OK;
 }
 

@@ -91,7 +91,8 @@ extern "C" int rf_index_create(rf_index_t** out, int dim, int64_t capacity_rows,
     RF_HIP(hipGetDeviceProperties(&prop, device));
     ix->num_cus = prop.multiProcessorCount;
   }
-  ix->ws_clean = nullptr;
+  for (int i = 0; i < 8; ++i) ix->ws_clean[i] = nullptr;
+  ix->ws_clean_next = 0;
   *out = ix;
   return RF_OK;
 }

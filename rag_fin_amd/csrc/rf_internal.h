@@ -31,7 +31,8 @@ struct rf_index {
   uint32_t* max_norm2; // device: bits of max squared row norm (float >= 0)
   size_t storage_bytes;
   int num_cus;         // compute units of `device` (sizes the co-resident fused grid)
-  mutable const void* ws_clean;  // workspace whose control block this index has zeroed
+  mutable const void* ws_clean[8];  // workspaces whose control block this index has zeroed
+  mutable int ws_clean_next;
 };
 
 // per-query candidate capacity of the fused scan: RF_CAND_SHARDS lists (picked by

@@ -125,7 +125,14 @@ class GpuIndex:
         return out
 
     # -- search --------------------------------------------------------------
-    def search_raw(self, q16, k: int, id_base: int = 0, want_exact: bool = False, out=None):
+    def new_workspace(self):
+        """An extra search workspace: one per batch in flight when several streams
+        search the same (immutable) index concurrently."""
+        torch = _torch()
+        return torch.empty(self.workspace_bytes, dtype=torch.uint8, device=self.device)
+
+    def search_raw(self, q16, k: int, id_base: int = 0, want_exact: bool = False, out=None,
+                   workspace=None):
         """Enqueue rf_search on the current stream; no host sync.  Returns
         (scores f32 [B,k], ids i64 [B,k], exact f64 [B,k] | None, flags u32 [B])."""
         torch = _torch()
@@ -145,7 +152,8 @@ class GpuIndex:
             _lib.check(self.lib.rf_search(
                 self.handle, c_void_p(q16.data_ptr()), B, k, id_base, c_void_p(scores.data_ptr()),
                 c_void_p(ids.data_ptr()), c_void_p(exact.data_ptr()) if exact is not None else None,
-                c_void_p(flags.data_ptr()), c_void_p(self.workspace.data_ptr()),
+                c_void_p(flags.data_ptr()),
+                c_void_p((workspace if workspace is not None else self.workspace).data_ptr()),
                 self.workspace_bytes, _lib.current_stream_ptr()))
         return scores, ids, exact, flags
 

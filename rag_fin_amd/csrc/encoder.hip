@@ -17,8 +17,9 @@
 //   k_linear<EPI>   Y^T = W X^T on the matrix cores: a workgroup owns 32 tokens x
 //                   384 output features (4 waves x 96); epilogues fused:
 //                   bias (QKV, K2) | bias+GELU (K5) | bias+residual+LayerNorm (K4, K6)
-//   k_attention     softmax(Q K^T / sqrt(32)) V per (sequence, head), online
-//                   softmax in fp32 on the vector ALU (< 2 % of the model FLOPs) (K3)
+//   k_attention_mfma softmax(Q K^T / sqrt(32)) V per (sequence, head) on the matrix cores
+//                   for T <= 256 (K3); k_attention = vector-ALU online-softmax form
+//                   kept for longer sequences
 //   k_pool_norm     mean over the sequence, L2-normalise                      (K7)
 #include "rf_internal.h"
 #include <new>
@@ -341,6 +342,132 @@ __global__ void __launch_bounds__(256) k_linear(
   }
 }
 
+// Attention on the matrix cores for sequences of <= 256 tokens (the model's
+// max_seq_length): one workgroup per (sequence, head); K rows and V^T in LDS.
+//   S^T = K Q^T   A = 32 keys (LDS rows padded to 80 B: conflict-free b128 reads),
+//                 B = 32 queries straight from HBM -> the accumulator holds the QUERY on
+//                 the lane and KEYS in registers, so the softmax is lane-local plus one
+//                 xor-32 shuffle;
+//   O^T = V^T P   the probability accumulator IS the B operand of the second product
+//                 (registers 8s..8s+7 -> fp16 = k-step s, rows in the order
+//                 16s + 8(j>>2) + 4h + (j&3); cdna_hip_programming.md section 3), and V^T
+//                 rows (stride T+4 halfs: conflict-free b64 reads) supply the A operand in
+//                 the same key order.
+#define ATT_MAX_KB 8
+__global__ void __launch_bounds__(256) k_attention_mfma(const _Float16* __restrict__ qkv,
+                                                        const int32_t* __restrict__ tok_off,
+                                                        _Float16* __restrict__ ctx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int b = blockIdx.x, head = blockIdx.y;
+  const int r0 = tok_off[b];
+  const int n = tok_off[b + 1] - r0;
+  if (n <= 0) return;
+  const int nkb = (n + 31) >> 5;
+  const int tpad = nkb * 32;
+  _Float16* ks = (_Float16*)lds;                       // [tpad][40]
+  _Float16* vt = ks + (size_t)tpad * 40;               // [32][tpad + 4]
+  const int vstride = tpad + 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  for (int i = tid; i < tpad * 4; i += 256) {
+    const int row = i >> 2, part = i & 3;
+    half8 kv, vv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kv[e] = (_Float16)0.f; vv[e] = (_Float16)0.f; }
+    if (row < n) {
+      const _Float16* src = qkv + (size_t)(r0 + row) * (3 * HID) + head * HEAD_DIM + part * 8;
+      kv = *(const half8*)(src + HID);
+      vv = *(const half8*)(src + 2 * HID);
+    }
+    *(half8*)(ks + row * 40 + part * 8) = kv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vt[(part * 8 + e) * vstride + row] = vv[e];
+  }
+  __syncthreads();
+  const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
+  for (int qb = wave; qb < nkb; qb += 4) {
+    const int q0 = qb * 32;
+    half8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[s][e] = (_Float16)0.f;
+      if (q0 + c < n)
+        qf[s] = *(const half8*)(qkv + (size_t)(r0 + q0 + c) * (3 * HID) + head * HEAD_DIM + 16 * s + 8 * h);
+    }
+    f32x16 sc[ATT_MAX_KB];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < ATT_MAX_KB; ++kb) {
+      if (kb < nkb) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const half8 a = *(const half8*)(ks + (kb * 32 + c) * 40 + 16 * s + 8 * h);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const float v = key < n ? acc[i] * scale : -INFINITY;
+          acc[i] = v;
+          m = fmaxf(m, v);
+        }
+        sc[kb] = acc;
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < ATT_MAX_KB; ++kb) {
+      if (kb < nkb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float pr = __expf(sc[kb][i] - m);
+          sc[kb][i] = pr;
+          l += pr;
+        }
+      }
+    }
+    l += __shfl_xor(l, 32);
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < ATT_MAX_KB; ++kb) {
+      if (kb < nkb) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          half8 pb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pb[j] = (_Float16)sc[kb][8 * s + j];
+          const _Float16* vrow = vt + c * vstride + kb * 32 + 16 * s + 4 * h;  // c = head dim here
+          const half4 lo = *(const half4*)vrow;
+          const half4 hi = *(const half4*)(vrow + 8);
+          half8 a;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb, o, 0, 0, 0);
+        }
+      }
+    }
+    if (q0 + c < n) {
+      const float inv = 1.f / l;
+      _Float16* dst = ctx + (size_t)(r0 + q0 + c) * HID + head * HEAD_DIM;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (_Float16)(o[4 * g + j] * inv);
+        *(half4*)(dst + 8 * g + 4 * h) = t;
+      }
+    }
+  }
+}
+
 // softmax(q k^T / sqrt(32)) v for one (sequence, head): K and V rows in LDS, one
 // query per thread, online softmax in fp32.
 __global__ void __launch_bounds__(256) k_attention(const _Float16* __restrict__ qkv,
@@ -497,6 +624,8 @@ extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const 
                                (int)attn_lds));
     attn_attr = attn_lds;
   }
+  const int tpad_max = (T + 31) / 32 * 32;
+  const size_t mfma_lds = (size_t)tpad_max * 80 + (size_t)32 * (tpad_max + 4) * 2;  // < 64 KB for T <= 256
   _Float16* x = ws.x;
   _Float16* y = ws.y;
   for (int l = 0; l < L; ++l) {
@@ -506,8 +635,12 @@ extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const 
     const uint4* ff2_t = enc->ff2_t + (size_t)l * HID * I / 8;
     launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
                             3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, st);
-    hipLaunchKernelGGL(k_attention, dim3(B, c.heads), dim3(256), attn_lds, st, ws.qkv, ws.tok_off,
-                       ws.ctx);
+    if (T <= 32 * ATT_MAX_KB)
+      hipLaunchKernelGGL(k_attention_mfma, dim3(B, c.heads), dim3(256), mfma_lds, st, ws.qkv, ws.tok_off,
+                         ws.ctx);
+    else
+      hipLaunchKernelGGL(k_attention, dim3(B, c.heads), dim3(256), attn_lds, st, ws.qkv, ws.tok_off,
+                         ws.ctx);
     launch_linear<EPI_BIAS_RES_LN>(ws.ctx, HID, ao_t, (const _Float16*)w.ao_b + (size_t)l * HID, y, HID,
                                    tiles, m_ptr, x, (const _Float16*)w.ln1_g + (size_t)l * HID,
                                    (const _Float16*)w.ln1_b + (size_t)l * HID, c.ln_eps, st);

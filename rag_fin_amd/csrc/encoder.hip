@@ -14,7 +14,7 @@
 // Kernels
 //   k_tok_offsets   lens -> packed row offsets
 //   k_embed_ln      word + position + type embedding gather, LayerNorm        (K1)
-//   k_linear<EPI>   Y^T = W X^T on the matrix cores: a workgroup owns 32 tokens x
+//   k_linear<EPI>   Y^T = W X^T on the matrix cores: a workgroup owns 32 or 64 tokens x
 //                   384 output features (4 waves x 96); epilogues fused:
 //                   bias (QKV, K2) | bias+GELU (K5) | bias+residual+LayerNorm (K4, K6)
 //   k_attention_mfma softmax(Q K^T / sqrt(32)) V per (sequence, head) on the matrix cores
@@ -23,6 +23,7 @@
 //   k_pool_norm     mean over the sequence, L2-normalise                      (K7)
 #include "rf_internal.h"
 #include <new>
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -236,109 +237,145 @@ __global__ void __launch_bounds__(256) k_embed_ln(
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RES_LN = 2 };
 
-// Y[tokens, N] = X[tokens, K] W^T + b with W tiled.  Workgroup = 32 tokens x 384
-// features (grid.y picks the 384-feature group); wave w owns features 96 w .. +96.
-// A operand = weight fragment (contiguous 1 KiB), B operand = 32 token rows, so the
-// accumulator holds TOKEN on the lane and FEATURES in registers: 4 consecutive
-// features per register quad -> 8-byte stores, and a lane-local LayerNorm sum.
-template <int EPI>
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output
+// step): one v_rcp, one v_exp and six fma instead of libm erff's ~50 instructions --
+// the GELU epilogue of the 1536-wide FFN GEMM evaluates it 50 M times per layer call.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float y = fmaf(t, 1.061405429f, -1.453152027f);
+  y = fmaf(t, y, 1.421413741f);
+  y = fmaf(t, y, -0.284496736f);
+  y = fmaf(t, y, 0.254829592f);
+  y *= t;
+  const float r = 1.0f - y * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float y) {
+  return 0.5f * y * (1.f + erf_fast(y * 0.70710678118654752f));
+}
+
+// Y[tokens, N] = X[tokens, K] W^T + b with W in the fragment tiling.  Workgroup =
+// 32*NTB tokens x 384 features (grid.y picks the 384-feature group); wave w owns
+// features 96 w .. +96 for all NTB token blocks: 3*NTB accumulators, each weight
+// fragment feeds NTB MFMAs.  A operand = weight fragment (one contiguous 1-KiB wave
+// load), B operand = 32 token rows read straight from the row-major activation
+// (16 B per lane; the four waves' identical reads hit L1).  No LDS and no barrier in
+// the k-loop: staging X through LDS with a barrier per 64-k stage was measured 25-75 %
+// SLOWER here (12-24 MFMAs between barriers cannot hide them at this occupancy).
+// The accumulator holds the TOKEN on the lane and FEATURES in registers: 4 consecutive
+// features per register quad -> 8-byte stores, and lane-local LayerNorm partial sums.
+template <int EPI, int NTB>   // NTB = 32-token blocks per workgroup
 __global__ void __launch_bounds__(256) k_linear(
     const _Float16* __restrict__ X, int K, const uint4* __restrict__ Wt,
     const _Float16* __restrict__ bias, _Float16* __restrict__ out, int ldo,
     const int32_t* __restrict__ m_ptr, const _Float16* __restrict__ res,
     const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta, float eps) {
-  __shared__ float red[2][4][32];
+  constexpr int LIN_TOK = 32 * NTB;
+  __shared__ float red[2][4][LIN_TOK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const int t0 = blockIdx.x * 32;
+  const int t0 = blockIdx.x * LIN_TOK;
   const int M = *m_ptr;
   if (t0 >= M) return;  // whole workgroup: no barrier is skipped by a subset
   const int KS = K / 16;
   const int fgroup = blockIdx.y * 384 + wave * 96;  // first feature of this wave
   const uint4* wbase = Wt + (size_t)(fgroup / 32) * KS * 64 + lane;
-  const _Float16* xrow = X + (size_t)(t0 + c) * K + h * 8;
 
-  f32x16 acc[3];
+  f32x16 acc[NTB][3];
 #pragma unroll
-  for (int fb = 0; fb < 3; ++fb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[fb][i] = 0.f;
-
-  for (int kk = 0; kk < KS; ++kk) {
-    const half8 b = *(const half8*)(xrow + kk * 16);
-#pragma unroll
-    for (int fb = 0; fb < 3; ++fb) {
-      const uint4 av = wbase[((size_t)fb * KS + kk) * 64];
-      acc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, av), b, acc[fb], 0, 0, 0);
-    }
-  }
-
-  const int token = t0 + c;
-  // acc[fb][4 g + j] = Y[token][fgroup + 32 fb + 8 g + 4 h + j]
-  float v[3][16];
-#pragma unroll
-  for (int fb = 0; fb < 3; ++fb)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int f = fgroup + 32 * fb + 8 * g + 4 * h;
-      const half4 bv = *(const half4*)(bias + f);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float y = acc[fb][4 * g + j] + (float)bv[j];
-        if (EPI == EPI_BIAS_GELU) y = 0.5f * y * (1.f + erff(y * 0.70710678118654752f));
-        v[fb][4 * g + j] = y;
-      }
-      if (EPI == EPI_BIAS_RES_LN) {
-        const half4 rv = *(const half4*)(res + (size_t)token * HID + f);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[fb][4 * g + j] += (float)rv[j];
-      }
-    }
-
-  float mu = 0.f, rstd = 1.f;
-  if (EPI == EPI_BIAS_RES_LN) {
-    // LayerNorm over the 384 features of a token: 48 per lane, x2 lane halves, x4 waves
-    float s = 0.f;
+  for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
     for (int fb = 0; fb < 3; ++fb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s += v[fb][i];
-    s += __shfl_xor(s, 32);
-    if (h == 0) red[0][wave][c] = s;
-    __syncthreads();
-    mu = (red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]) * (1.f / HID);
-    float q = 0.f;
+      for (int i = 0; i < 16; ++i) acc[tb][fb][i] = 0.f;
+
+  {
+    const _Float16* xrow = X + (size_t)(t0 + c) * K + h * 8;
+    for (int kk = 0; kk < KS; ++kk) {
+      half8 bfr[NTB];
 #pragma unroll
-    for (int fb = 0; fb < 3; ++fb)
+      for (int tb = 0; tb < NTB; ++tb) bfr[tb] = *(const half8*)(xrow + (size_t)(32 * tb) * K + kk * 16);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) q += (v[fb][i] - mu) * (v[fb][i] - mu);
-    q += __shfl_xor(q, 32);
-    if (h == 0) red[1][wave][c] = q;
-    __syncthreads();
-    rstd = rsqrtf((red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]) * (1.f / HID) + eps);
+      for (int fb = 0; fb < 3; ++fb) {
+        const half8 a = __builtin_bit_cast(half8, wbase[((size_t)fb * KS + kk) * 64]);
+#pragma unroll
+        for (int tb = 0; tb < NTB; ++tb)
+          acc[tb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[tb], acc[tb][fb], 0, 0, 0);
+      }
+    }
   }
 
-  if (token < M) {
+  // acc[tb][fb][4 g + j] = Y[t0 + 32 tb + c][fgroup + 32 fb + 8 g + 4 h + j]
+#pragma unroll
+  for (int tb = 0; tb < NTB; ++tb) {
+    const int token = t0 + tb * 32 + c;
+    float v[3][16];
 #pragma unroll
     for (int fb = 0; fb < 3; ++fb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int f = fgroup + 32 * fb + 8 * g + 4 * h;
-        half4 o;
-        if (EPI == EPI_BIAS_RES_LN) {
-          const half4 gv = *(const half4*)(gamma + f);
-          const half4 be = *(const half4*)(beta + f);
+        const half4 bv = *(const half4*)(bias + f);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            o[j] = (_Float16)((v[fb][4 * g + j] - mu) * rstd * (float)gv[j] + (float)be[j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[fb][4 * g + j];
+        for (int j = 0; j < 4; ++j) {
+          float y = acc[tb][fb][4 * g + j] + (float)bv[j];
+          if (EPI == EPI_BIAS_GELU) y = gelu_erf(y);
+          v[fb][4 * g + j] = y;
         }
-        *(half4*)(out + (size_t)token * ldo + f) = o;
+        if (EPI == EPI_BIAS_RES_LN) {
+          const half4 rv = *(const half4*)(res + (size_t)token * HID + f);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[fb][4 * g + j] += (float)rv[j];
+        }
       }
+
+    float mu = 0.f, rstd = 1.f;
+    if (EPI == EPI_BIAS_RES_LN) {
+      // LayerNorm over the 384 features of a token: 48 per lane, x2 lane halves, x4 waves
+      float s = 0.f;
+#pragma unroll
+      for (int fb = 0; fb < 3; ++fb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += v[fb][i];
+      s += __shfl_xor(s, 32);
+      if (h == 0) red[0][wave][tb * 32 + c] = s;
+      __syncthreads();
+      const int tc = tb * 32 + c;
+      mu = (red[0][0][tc] + red[0][1][tc] + red[0][2][tc] + red[0][3][tc]) * (1.f / HID);
+      float q = 0.f;
+#pragma unroll
+      for (int fb = 0; fb < 3; ++fb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q += (v[fb][i] - mu) * (v[fb][i] - mu);
+      q += __shfl_xor(q, 32);
+      if (h == 0) red[1][wave][tc] = q;
+      __syncthreads();
+      rstd = rsqrtf((red[1][0][tc] + red[1][1][tc] + red[1][2][tc] + red[1][3][tc]) * (1.f / HID) + eps);
+    }
+
+    if (token < M) {
+#pragma unroll
+      for (int fb = 0; fb < 3; ++fb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f = fgroup + 32 * fb + 8 * g + 4 * h;
+          half4 o;
+          if (EPI == EPI_BIAS_RES_LN) {
+            const half4 gv = *(const half4*)(gamma + f);
+            const half4 be = *(const half4*)(beta + f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              o[j] = (_Float16)((v[fb][4 * g + j] - mu) * rstd * (float)gv[j] + (float)be[j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[fb][4 * g + j];
+          }
+          *(half4*)(out + (size_t)token * ldo + f) = o;
+        }
+    }
   }
 }
 
@@ -571,12 +608,16 @@ __global__ void __launch_bounds__(192) k_pool_norm(const _Float16* __restrict__ 
 }
 
 // ---- forward pass -----------------------------------------------------------------------
+// the LayerNorm-fused GEMMs have only 384 output features (one feature group), so
+// they take 32-token tiles to put twice as many workgroups on the chip
 template <int EPI>
 static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Float16* bias,
-                          _Float16* out, int N, int tiles, const int32_t* m_ptr, const _Float16* res,
+                          _Float16* out, int N, int tokens, const int32_t* m_ptr, const _Float16* res,
                           const _Float16* g, const _Float16* b, float eps, hipStream_t st) {
-  hipLaunchKernelGGL(k_linear<EPI>, dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out, N,
-                     m_ptr, res, g, b, eps);
+  constexpr int NTB = EPI == EPI_BIAS_RES_LN ? 1 : 2;
+  const int tiles = (tokens + 32 * NTB - 1) / (32 * NTB);
+  hipLaunchKernelGGL((k_linear<EPI, NTB>), dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out,
+                     N, m_ptr, res, g, b, eps);
 }
 
 extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev,
@@ -604,7 +645,7 @@ extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const 
   const int I = c.intermediate, L = c.layers;
   EncWs ws;
   enc_carve((unsigned char*)workspace_dev, B, T, I, &ws);
-  const int tiles = (int)(((size_t)B * T + 31) / 32);
+  const int tiles = B * T;   // token slots; launch_linear turns them into tiles
   const int32_t* m_ptr = ws.tok_off + B;
 
   hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off);

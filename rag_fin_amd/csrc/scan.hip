@@ -301,13 +301,20 @@ int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_
   const int KS = ix->KS;
   const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
   const int WAVES = waves_per_wg(KS);
-  // one workgroup per CU, SAMPLE_BPW blocks per wave, spread evenly over the corpus
+  // Sample ~1/16 of the corpus, spread evenly: candidates per query ~ k * N / n_sample
+  // stay ~16 k whatever N is, and a small corpus does not pay a sample pass as long as
+  // its scan.  At least 64 workgroups (partitions) so the k-th largest exists for
+  // k <= 64, at most RF_SAMPLE_WGS workgroups x SAMPLE_BPW blocks per wave.
   const int SAMPLE_BPW = tuning().sample_bpw;
-  int grid = RF_SAMPLE_WGS;
-  if ((uint32_t)grid * WAVES > nblk) grid = (int)(nblk / WAVES);
-  if (grid < 1) grid = 1;
-  uint32_t n_work = (uint32_t)grid * WAVES * SAMPLE_BPW;
+  uint32_t n_work = nblk / 16;
+  const uint32_t lo = 64u * WAVES, hi = (uint32_t)RF_SAMPLE_WGS * WAVES * SAMPLE_BPW;
+  if (n_work < lo) n_work = lo;
+  if (n_work > hi) n_work = hi;
   if (n_work > nblk) n_work = nblk;
+  const uint32_t per_wg = (uint32_t)WAVES * (n_work >= (uint32_t)RF_SAMPLE_WGS * WAVES ? SAMPLE_BPW : 1);
+  int grid = (int)((n_work + per_wg - 1) / per_wg);
+  if (grid > RF_SAMPLE_WGS) grid = RF_SAMPLE_WGS;
+  if (grid < 1) grid = 1;
   const uint32_t bstride = nblk / n_work;  // >= 1
   ScanParams p{};
   p.corpus = ix->tiles;

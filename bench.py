@@ -77,11 +77,19 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+    if os.environ.get("RAGFIN_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        # RAGFIN_DIST_BACKEND=gloo + RAGFIN_SHARE_GPU=1: rehearsal of the N>1 code path
+        # on a single-GPU box (all ranks on cuda:0, collectives over gloo)
+        backend = os.environ.get("RAGFIN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from oracle import search as osearch
     from rag_fin_amd.sharded import HipShardBackend, ShardedSearcher

@@ -79,7 +79,13 @@ class ShardedSearcher:
         packed = torch.cat([exact.view(torch.int64), ids], dim=1).contiguous()
         # concatenated-along-dim-0 output: the form both RCCL and gloo accept
         flat = torch.empty((self.world * B, 2 * k), dtype=torch.int64, device=packed.device)
-        self.dist.all_gather_into_tensor(flat, packed, group=self.group)
+        if packed.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # rehearsal path (gloo has no device all-gather): stage through the host
+            host = torch.empty(flat.shape, dtype=torch.int64)
+            self.dist.all_gather_into_tensor(host, packed.cpu(), group=self.group)
+            flat.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(flat, packed, group=self.group)
         gathered = flat.view(self.world, B, 2 * k)
         exact_all = gathered[:, :, :k].contiguous().view(torch.float64)
         ids_all = gathered[:, :, k:].contiguous()

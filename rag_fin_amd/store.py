@@ -387,6 +387,61 @@ class CorpusStore:
             out.append(hits)
         return out
 
+    # -- persistence -------------------------------------------------
+    # The reference leans on the Milvus server for durability and re-creates the
+    # collection on every ingest ("chunking_storing (1).py":25-28); an in-process store
+    # needs its own format.  Directory layout:
+    #   vectors.f16   raw little-endian fp16, row-major [n, dim]   (np.memmap-able)
+    #   columns.json  {"name", "dim", "metric_type", "n", "columns": {field: [...]}}
+    def save(self, path: str, chunk_rows: int = 1 << 18) -> None:
+        import json
+        import os
+        os.makedirs(path, exist_ok=True)
+        n = self.num_entities
+        tmp = os.path.join(path, "vectors.f16.tmp")
+        with open(tmp, "wb") as f:
+            for s0 in range(0, n, chunk_rows):
+                rows = np.arange(s0, min(n, s0 + chunk_rows), dtype=np.int64)
+                f.write(self.index.get_rows(rows).cpu().numpy().tobytes())
+        os.replace(tmp, os.path.join(path, "vectors.f16"))
+        meta = {"format": "ragfin-corpus-v1", "name": self.name, "dim": self.dim,
+                "metric_type": self.metric_type, "n": n, "columns": self.columns}
+        tmp = os.path.join(path, "columns.json.tmp")
+        with open(tmp, "w", encoding="utf-8") as f:
+            json.dump(meta, f, ensure_ascii=False)
+        os.replace(tmp, os.path.join(path, "columns.json"))
+
+    @classmethod
+    def load_from(cls, path: str, device=None, capacity: int | None = None,
+                  chunk_rows: int = 1 << 18) -> "CorpusStore":
+        """Memory-map vectors.f16 and stream it into HBM in chunks (never the whole file
+        in host RAM)."""
+        import json
+        import os
+        torch = _torch()
+        with open(os.path.join(path, "columns.json"), encoding="utf-8") as f:
+            meta = json.load(f)
+        if meta.get("format") != "ragfin-corpus-v1":
+            raise ValueError(f"{path}: not a ragfin corpus directory")
+        n, dim = int(meta["n"]), int(meta["dim"])
+        st = cls(meta["name"], dim=dim, capacity=max(capacity or 0, n, 1), device=device,
+                 metric_type=meta["metric_type"])
+        if n:
+            expect = n * dim * 2
+            got = os.path.getsize(os.path.join(path, "vectors.f16"))
+            if got != expect:
+                raise ValueError(f"{path}/vectors.f16 holds {got} bytes, expected {expect}")
+            mm = np.memmap(os.path.join(path, "vectors.f16"), dtype=np.float16, mode="r", shape=(n, dim))
+            for s0 in range(0, n, chunk_rows):
+                st.index.add(torch.from_numpy(np.ascontiguousarray(mm[s0:s0 + chunk_rows])).to(st.index.device))
+            del mm
+        cols = meta["columns"]
+        if any(len(cols[f]) != n for f in SCALAR_FIELDS):
+            raise ValueError(f"{path}: column lengths do not match n={n}")
+        st.columns = {f: list(cols[f]) for f in SCALAR_FIELDS}
+        st._pk_row = {pk: i for i, pk in enumerate(st.columns["id"])}
+        return st
+
     # -- scalar queries ----------------------------------------------------------------
     def query(self, expr: str = "", limit: int | None = None,
               output_fields: Iterable[str] | None = None) -> list[dict]:

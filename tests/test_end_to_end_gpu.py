@@ -134,3 +134,27 @@ def test_float32_insert_path_and_drop(gpu_device):
     assert hits[0].id == "k7" and abs(hits[0].score - 1) < 2e-3
     st.drop()
     assert st.num_entities == 0 and st.search(vec[:1], limit=3) == [[]]
+
+
+def test_save_and_load_round_trip(rig, tmp_path, gpu_device):
+    """On-disk corpus format: vectors + scalar columns survive
+    a save/load cycle bit for bit and search results are unchanged."""
+    from rag_fin_amd.store import CorpusStore
+    store = rig["store"]
+    store.save(str(tmp_path / "corpus"))
+    assert (tmp_path / "corpus" / "vectors.f16").stat().st_size == 16 * 384 * 2
+    again = CorpusStore.load_from(str(tmp_path / "corpus"), device=gpu_device)
+    assert again.num_entities == 16 and again.columns == store.columns
+    a = store.index.get_rows(np.arange(16)).cpu().numpy().view(np.uint16)
+    b = again.index.get_rows(np.arange(16)).cpu().numpy().view(np.uint16)
+    assert np.array_equal(a, b)
+    q = rig["emb"].encode([QUESTIONS[0]])
+    h1 = store.search(q, "embedding", {"metric_type": "COSINE"}, 5, output_fields=["id"])[0]
+    h2 = again.search(q, "embedding", {"metric_type": "COSINE"}, 5, output_fields=["id"])[0]
+    assert [h.id for h in h1] == [h.id for h in h2] and [h.score for h in h1] == [h.score for h in h2]
+    # appending after a load keeps working (resume)
+    again.add(["extra"], ["t"], np.ones((1, 384), np.float32), ["p"], ["c"], ["s"], [1.0])
+    assert again.num_entities == 17 and again.query(expr='id in ["extra"]')[0]["id"] == "extra"
+    with pytest.raises(ValueError):
+        (tmp_path / "corpus" / "vectors.f16").write_bytes(b"xx")
+        CorpusStore.load_from(str(tmp_path / "corpus"), device=gpu_device)

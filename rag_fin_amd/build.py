@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libragfin_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["index.hip", "scan.hip", "scan_fused.hip", "merge.hip", "api.hip", "encoder.hip"]
+SOURCES = ["index.hip", "scan.hip", "scan_fused.hip", "scan_wide.hip", "merge.hip", "api.hip", "encoder.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

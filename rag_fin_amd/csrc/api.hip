@@ -13,14 +13,14 @@ static size_t carve(unsigned char* base, rf_workspace* ws) {
     off = align_up(off + bytes, 256);
     return p;
   };
-  float* thr = (float*)take(RF_QCHUNK * sizeof(float));
-  float* eps = (float*)take(RF_QCHUNK * sizeof(float));
-  uint32_t* cnt = (uint32_t*)take((size_t)RF_QCHUNK * RF_CAND_SHARDS * sizeof(uint32_t));
-  uint32_t* gmax = (uint32_t*)take((size_t)RF_QCHUNK * RF_MAX_K * sizeof(uint32_t));
+  float* thr = (float*)take(RF_QWIDE * sizeof(float));
+  float* eps = (float*)take(RF_QWIDE * sizeof(float));
+  uint32_t* cnt = (uint32_t*)take((size_t)RF_QWIDE * RF_CAND_SHARDS * sizeof(uint32_t));
+  uint32_t* gmax = (uint32_t*)take((size_t)RF_QWIDE * RF_MAX_K * sizeof(uint32_t));
   uint32_t* bar = (uint32_t*)take(16 * sizeof(uint32_t));
   const size_t ctl_bytes = off;
-  float* pmax = (float*)take((size_t)RF_QCHUNK * RF_SAMPLE_WGS * sizeof(float));
-  uint2* cand = (uint2*)take((size_t)RF_QCHUNK * RF_CAND_SHARDS * RF_SHARD_CAP * sizeof(uint2));
+  float* pmax = (float*)take((size_t)RF_QWIDE * RF_SAMPLE_WGS * sizeof(float));
+  uint2* cand = (uint2*)take((size_t)RF_QWIDE * RF_CAND_SHARDS * RF_SHARD_CAP * sizeof(uint2));
   double* exs = (double*)take((size_t)RF_QCHUNK * RF_EX_WGS * RF_MAX_K * sizeof(double));
   int64_t* exr = (int64_t*)take((size_t)RF_QCHUNK * RF_EX_WGS * RF_MAX_K * sizeof(int64_t));
   if (ws) {
@@ -85,6 +85,15 @@ static bool use_fused() {
   return rf_tuning_fused != 0;
 }
 
+// RF_WIDE=0 answers large batches with 64-query sweeps only (A/B runs)
+static bool use_wide() {
+  static const bool on = [] {
+    const char* v = getenv("RF_WIDE");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
 // The control block (counters, group maxima, hand-off words) must be zero when a
 // search starts.  k_merge leaves it zero for the next call; a workspace this index
 // has not used before is zeroed here once.
@@ -134,11 +143,25 @@ extern "C" int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, 
   rc = prepare_workspace(ix, workspace_dev, ws, st);
   if (rc != RF_OK) return rc;
   const int dim = ix->dim;
-  for (int q0 = 0; q0 < B; q0 += RF_QCHUNK) {
-    const int nb = (B - q0) < RF_QCHUNK ? (B - q0) : RF_QCHUNK;
+  const bool wide_ok = !use_fused() && rf_wide_supported(ix) && use_wide();
+  for (int q0 = 0; q0 < B;) {
+    const int left = B - q0;
+    // more than one 64-query sweep left and dim 384: one wide sweep of up to 256 queries
+    const bool wide = wide_ok && left > RF_QCHUNK;
+    const int nb = wide ? (left < RF_QWIDE ? left : RF_QWIDE) : (left < RF_QCHUNK ? left : RF_QCHUNK);
     const int JB = nb <= 32 ? 1 : 2;
     const _Float16* qc = (const _Float16*)q_dev + (size_t)q0 * dim;
-    if (use_fused()) {
+    if (wide) {
+      int P = 0;
+      if (ix->size > RF_SMALL_ROWS) {
+        rc = rf_launch_wide_sample(ix, qc, nb, ws, &P, st);
+        if (rc != RF_OK) return rc;
+      }
+      rc = rf_launch_threshold(ix, qc, nb, k, P, ws, st);
+      if (rc != RF_OK) return rc;
+      rc = rf_launch_wide_emit(ix, qc, nb, ws, st);
+      if (rc != RF_OK) return rc;
+    } else if (use_fused()) {
       rc = rf_launch_fused(ix, qc, nb, JB, k, ws, st);
       if (rc != RF_OK) return rc;
     } else {
@@ -156,6 +179,7 @@ extern "C" int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, 
                          ids_dev + (size_t)q0 * k, exact_dev ? exact_dev + (size_t)q0 * k : nullptr,
                          flags_dev ? flags_dev + q0 : nullptr, st);
     if (rc != RF_OK) return rc;
+    q0 += nb;
   }
   return RF_OK;
 }

@@ -525,7 +525,8 @@ __global__ void __launch_bounds__(EX_THREADS) k_merge_shards(
 // ---- host side --------------------------------------------------------------------------
 int rf_launch_threshold(const rf_index* ix, const void* q, int B, int k, int P,
                         const rf_workspace& ws, hipStream_t st) {
-  hipLaunchKernelGGL(k_threshold, dim3(RF_QCHUNK), dim3(64), 0, st, (const _Float16*)q, B, ix->dim,
+  // one wave per query slot of the sweep (64, or up to RF_QWIDE for a wide sweep)
+  hipLaunchKernelGGL(k_threshold, dim3(B > RF_QCHUNK ? RF_QWIDE : RF_QCHUNK), dim3(64), 0, st, (const _Float16*)q, B, ix->dim,
                      k, ws.pmax, P, ix->max_norm2, ws.thr, ws.eps, ws.cand_cnt);
   RF_HIP(hipGetLastError());
   return RF_OK;

@@ -35,6 +35,8 @@ struct rf_index {
   mutable int ws_clean_next;
 };
 
+// queries per wide sweep (scan_wide.hip); every per-query workspace array is sized for it
+#define RF_QWIDE 256
 // per-query candidate capacity of the fused scan: RF_CAND_SHARDS lists (picked by
 // workgroup id) of RF_SHARD_CAP entries; the merge handles RF_CAND_CAP in total
 #define RF_CAND_CAP 8192
@@ -84,6 +86,11 @@ int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_wo
 int rf_launch_debug_scores(const rf_index* ix, const void* q, int B, int64_t n, float* out,
                            hipStream_t st);
 int rf_scan_supported_dim(int dim);
+// scan_wide.hip
+int rf_wide_supported(const rf_index* ix);
+int rf_launch_wide_sample(const rf_index* ix, const void* q, int B, const rf_workspace& ws, int* P_out,
+                          hipStream_t st);
+int rf_launch_wide_emit(const rf_index* ix, const void* q, int B, const rf_workspace& ws, hipStream_t st);
 // scan_fused.hip
 int rf_launch_fused(const rf_index* ix, const void* q, int B, int JB, int k, const rf_workspace& ws,
                     hipStream_t st);

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_scan(ScanParams p) {
   }
   EmitState es;
   es.cnt = 0;
+  es.q_base = 0;
   if (MODE == MODE_EMIT) {
     es.s_row = (uint32_t*)tail + wave * SCAP;
     es.s_score = (float*)((uint32_t*)tail + WAVES * SCAP) + wave * SCAP;

@@ -55,6 +55,7 @@ struct EmitState {
   float* s_score;      // [SCAP]
   uint32_t* s_q;       // [SCAP]
   uint32_t cnt;        // wave-uniform
+  uint32_t q_base;     // query index of this wave's column 0 (wide sweep: 32 * wave)
 };
 
 template <class P>
@@ -105,7 +106,7 @@ __device__ __forceinline__ void emit_slow(const f32x16 (&acc)[JB], const float (
       const uint32_t slot = es.cnt + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       es.s_row[slot] = row0 + (uint32_t)((i & 3) + 8 * (i >> 2) + 4 * h);
       es.s_score[slot] = s;
-      es.s_q[slot] = (uint32_t)((b >> 4) * 32 + (lane & 31));
+      es.s_q[slot] = es.q_base + (uint32_t)((b >> 4) * 32 + (lane & 31));
     }
     es.cnt += n;
     bits &= bits - 1u;

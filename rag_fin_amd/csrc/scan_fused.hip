@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_scan_fused(FusedParams p) {
   }
   EmitState es;
   es.cnt = 0;
+  es.q_base = 0;
   es.s_row = stage + wave * SCAP;
   es.s_score = (float*)(stage + WAVES * SCAP) + wave * SCAP;
   es.s_q = stage + 2 * WAVES * SCAP + wave * SCAP;

@@ -216,3 +216,28 @@ def test_full_size_1m_properties(gpu_device, dim):
     assert torch.equal(i2, i[:6]) and torch.equal(e2, e[:6])
     s3, i3, e3, _ = ix.search_raw(q[5:6], 10, want_exact=True)
     assert torch.equal(i3, i[5:6]) and torch.equal(e3, e[5:6])
+
+
+@pytest.mark.parametrize("n,b,k", [(40_000, 256, 10), (25_000, 300, 10), (3_000, 100, 10), (70_000, 65, 64),
+                                   (8_193, 129, 5)])
+def test_wide_sweep_parity(gpu_device, n, b, k):
+    """Batches above 64 queries at dim 384 take the wide sweep (scan_wide.hip: up to
+    256 queries per corpus pass); same oracle, same bit-exact bar."""
+    c = osearch.synth_unit_rows(n, 384, 77)
+    q = osearch.synth_unit_rows(b, 384, 78)
+    c[1234 % n] = q[b - 1]                       # a planted exact match for the last query
+    ix = make_index(c, gpu_device)
+    check_against_oracle(ix, q, c, k, gpu_device)
+
+
+def test_wide_sweep_equals_narrow_sweeps(gpu_device, monkeypatch):
+    """The same 200 queries answered by one wide sweep and by 64-query sweeps."""
+    import torch
+    c = osearch.synth_unit_rows(120_000, 384, 5)
+    q = torch.from_numpy(osearch.synth_unit_rows(200, 384, 6)).to(gpu_device)
+    ix = make_index(c, gpu_device)
+    s1, i1, e1, f1 = ix.search_raw(q, 10, want_exact=True)
+    parts = [ix.search_raw(q[a:a + 64].contiguous(), 10, want_exact=True) for a in range(0, 200, 64)]
+    torch.cuda.synchronize()
+    assert int(f1.abs().sum()) == 0
+    assert torch.equal(i1, torch.cat([p[1] for p in parts])) and torch.equal(e1, torch.cat([p[2] for p in parts]))

@@ -70,37 +70,69 @@ __global__ void __launch_bounds__(WIDE_WAVES * 64, 2) k_scan_wide(WideParams p) 
   // work items of this WORKGROUP: w = blockIdx.x, + gridDim.x, ...
   const uint32_t G = gridDim.x;
   const uint32_t cnt = (p.n_work > blockIdx.x) ? (p.n_work - blockIdx.x + G - 1) / G : 0u;
+  if (cnt == 0) return;   // whole workgroup (cnt is workgroup-uniform): no barrier is skipped by a subset
+  // Every load below is UNCONDITIONAL (indices past the end are clamped to the last
+  // block and their results discarded): with loads under `if (i + 3 < cnt)` hipcc
+  // cannot count them and waits vmcnt(0) before every LDS write, which exposes a full
+  // HBM latency per block (measured 260 us instead of ~130 us).
   auto piece = [&](uint32_t i, int j) {
-    const uint32_t b = (blockIdx.x + i * G) * p.bstride;
+    const uint32_t ic = i < cnt ? i : cnt - 1;
+    const uint32_t b = (blockIdx.x + ic * G) * p.bstride;
     return p.corpus + ((size_t)b * WIDE_KS + wave * WIDE_PIECES + j) * 64 + lane;
   };
 
   u32x4 ring[WIDE_DEPTH][WIDE_PIECES];
 #pragma unroll
   for (int d = 0; d < WIDE_DEPTH; ++d)
-    if ((uint32_t)d < cnt) {
 #pragma unroll
-      for (int j = 0; j < WIDE_PIECES; ++j) ring[d][j] = ld_frag(piece(d, j));
-    }
+    for (int j = 0; j < WIDE_PIECES; ++j) ring[d][j] = ld_frag(piece(d, j));
 
-  // one block: publish my pieces, barrier, re-arm the ring slot, 24 MFMAs, filter
-  auto step = [&](uint32_t i, u32x4 (&mine)[WIDE_PIECES]) {
-    u32x4* slot = slots + (i & 1u) * (WIDE_KS * 64);
+  // Block i is computed from LDS slot i & 1 while block i+1 is being published to the
+  // other slot: one barrier per block, and the LDS writes (with their wait on HBM) run
+  // under the previous block's MFMAs instead of in front of the barrier.
+  //   barrier_i  => every wave has finished block i-1 (its slot may be overwritten)
+  //                 and every piece of block i (written during step i-1) is in LDS
+  auto publish = [&](uint32_t blk, u32x4 (&mine)[WIDE_PIECES]) {
+    u32x4* dst = slots + (blk & 1u) * (WIDE_KS * 64);
 #pragma unroll
-    for (int j = 0; j < WIDE_PIECES; ++j) slot[(wave * WIDE_PIECES + j) * 64 + lane] = mine[j];
+    for (int j = 0; j < WIDE_PIECES; ++j) dst[(wave * WIDE_PIECES + j) * 64 + lane] = mine[j];
+  };
+  auto step = [&](uint32_t i, u32x4 (&mine)[WIDE_PIECES]) {   // `mine` holds block i+1
+    const u32x4* slot = slots + (i & 1u) * (WIDE_KS * 64);
     __syncthreads();
-    if (i + WIDE_DEPTH < cnt) {
+    publish(i + 1, mine);
 #pragma unroll
-      for (int j = 0; j < WIDE_PIECES; ++j) mine[j] = ld_frag(piece(i + WIDE_DEPTH, j));
-    }
+    for (int j = 0; j < WIDE_PIECES; ++j) mine[j] = ld_frag(piece(i + 1 + WIDE_DEPTH, j));
     f32x16 acc[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+    // A fragments come from LDS in batches of 6, double-buffered and pinned with
+    // sched_barrier: left alone hipcc keeps only TWO fragments in flight, so every
+    // second MFMA waits a full LDS latency (measured: 31 % MFMA utilisation, 252 us).
+    {
+      constexpr int NB = 6;
+      u32x4 a0[NB], a1[NB];
 #pragma unroll
-    for (int kk = 0; kk < WIDE_KS; ++kk)
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, slot[kk * 64 + lane]),
-                                                      __builtin_bit_cast(half8, qf[kk]), acc[0], 0, 0, 0);
-    const uint32_t row0 = (blockIdx.x + i * G) * p.bstride * 32u;
+      for (int j = 0; j < NB; ++j) a0[j] = slot[(0 * NB + j) * 64 + lane];
+#pragma unroll
+      for (int g = 0; g < WIDE_KS / NB; ++g) {
+        u32x4(&cur)[NB] = (g & 1) ? a1 : a0;
+        u32x4(&nxt)[NB] = (g & 1) ? a0 : a1;
+        if (g + 1 < WIDE_KS / NB) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) nxt[j] = slot[((g + 1) * NB + j) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, cur[j]),
+                                                          __builtin_bit_cast(half8, qf[g * NB + j]),
+                                                          acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // padding steps (i >= cnt) re-score the last block; row0 = n_rows masks every row
+    const uint32_t row0 = i < cnt ? (blockIdx.x + i * G) * p.bstride * 32u : p.n_rows;
     if (MODE == MODE_SAMPLE) {
       if (row0 + 32u > p.n_rows) {
 #pragma unroll
@@ -109,17 +141,24 @@ __global__ void __launch_bounds__(WIDE_WAVES * 64, 2) k_scan_wide(WideParams p) 
       }
       pm = fmaxf(pm, max16(acc[0]));
     } else {
-      const bool hit = max16(acc[0]) >= th[0];
+      // 16 compares OR-ed on the scalar unit: fmaxf on MFMA results costs an extra
+      // canonicalising v_max per element, a compare does not
+      bool hit = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hit |= acc[0][r] >= th[0];
       if (__ballot(hit) != 0ull) {
         emit_slow<1>(acc, th, row0, lane, es, p);
       }
     }
   };
 
-  for (uint32_t i = 0; i < cnt; i += WIDE_DEPTH) {
-    step(i, ring[0]);
-    if (i + 1 < cnt) step(i + 1, ring[1]);
-    if (i + 2 < cnt) step(i + 2, ring[2]);
+  publish(0, ring[0]);
+#pragma unroll
+  for (int j = 0; j < WIDE_PIECES; ++j) ring[0][j] = ld_frag(piece(WIDE_DEPTH, j));
+  for (uint32_t i = 0; i < cnt; i += WIDE_DEPTH) {   // cnt rounded up to a multiple of the ring depth
+    step(i, ring[1]);        // ring[(i + 1) % 3] holds block i + 1
+    step(i + 1, ring[2]);
+    step(i + 2, ring[0]);
   }
 
   if (MODE == MODE_EMIT) {

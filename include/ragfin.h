@@ -109,6 +109,15 @@ int rf_search_exhaustive(const rf_index_t* ix, const void* q_dev, int B, int k,
                          int64_t id_base, float* scores_dev, int64_t* ids_dev,
                          double* exact_dev, void* workspace_dev, size_t workspace_bytes,
                          void* stream);
+/* Paging for limits above RF_MAX_K (the reference's hybrid consumer asks for
+ * limit=1000, graph_cons.py:275-281): the next k hits ranked strictly AFTER the
+ * per-query bound (after_score_dev fp64 [B], after_id_dev int64 [B] = the last hit
+ * of the previous page, ids including id_base).  Exhaustive fp64 path. */
+int rf_search_exhaustive_after(const rf_index_t* ix, const void* q_dev, int B, int k,
+                               int64_t id_base, const double* after_score_dev,
+                               const int64_t* after_id_dev, float* scores_dev, int64_t* ids_dev,
+                               double* exact_dev, void* workspace_dev, size_t workspace_bytes,
+                               void* stream);
 /* Cross-shard merge after the RCCL all-gather: in [W, B, k] (exact fp64, id
  * int64) -> out [B, k] by (score desc, id asc).  New in this build (the
  * reference is single-process); see SURVEY.md 8e. */

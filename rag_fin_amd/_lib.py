@@ -62,6 +62,8 @@ SIGNATURES = {
                                   POINTER(c_float)]),
     "rf_search_exhaustive": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rf_search_exhaustive_after": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rf_merge_shards": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p]),
     "rf_set_tuning": (c_int, [c_char_p, c_int]),

@@ -222,12 +222,11 @@ extern "C" int rf_search_profile(const rf_index_t* ix, const void* q_dev, int B,
   return rc;
 }
 
-extern "C" int rf_search_exhaustive(const rf_index_t* ix, const void* q_dev, int B, int k,
-                                    int64_t id_base, float* scores_dev, int64_t* ids_dev,
-                                    double* exact_dev, void* workspace_dev, size_t workspace_bytes,
-                                    void* stream) {
-  int rc = check_search_args("rf_search_exhaustive", ix, q_dev, B, k, scores_dev, ids_dev,
-                             workspace_dev, workspace_bytes);
+static int exhaustive_impl(const char* fn, const rf_index_t* ix, const void* q_dev, int B, int k,
+                           int64_t id_base, float* scores_dev, int64_t* ids_dev, double* exact_dev,
+                           const double* after_s, const int64_t* after_r, void* workspace_dev,
+                           size_t workspace_bytes, void* stream) {
+  int rc = check_search_args(fn, ix, q_dev, B, k, scores_dev, ids_dev, workspace_dev, workspace_bytes);
   if (rc != RF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (ix->size == 0) {
@@ -241,10 +240,32 @@ extern "C" int rf_search_exhaustive(const rf_index_t* ix, const void* q_dev, int
     const int nb = (B - q0) < RF_QCHUNK ? (B - q0) : RF_QCHUNK;
     rc = rf_launch_exhaustive(ix, (const _Float16*)q_dev + (size_t)q0 * ix->dim, nb, k, id_base, ws,
                               scores_dev + (size_t)q0 * k, ids_dev + (size_t)q0 * k,
-                              exact_dev ? exact_dev + (size_t)q0 * k : nullptr, st);
+                              exact_dev ? exact_dev + (size_t)q0 * k : nullptr,
+                              after_s ? after_s + q0 : nullptr, after_r ? after_r + q0 : nullptr, st);
     if (rc != RF_OK) return rc;
   }
   return RF_OK;
+}
+
+extern "C" int rf_search_exhaustive(const rf_index_t* ix, const void* q_dev, int B, int k,
+                                    int64_t id_base, float* scores_dev, int64_t* ids_dev,
+                                    double* exact_dev, void* workspace_dev, size_t workspace_bytes,
+                                    void* stream) {
+  return exhaustive_impl("rf_search_exhaustive", ix, q_dev, B, k, id_base, scores_dev, ids_dev,
+                         exact_dev, nullptr, nullptr, workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int rf_search_exhaustive_after(const rf_index_t* ix, const void* q_dev, int B, int k,
+                                          int64_t id_base, const double* after_score_dev,
+                                          const int64_t* after_id_dev, float* scores_dev,
+                                          int64_t* ids_dev, double* exact_dev, void* workspace_dev,
+                                          size_t workspace_bytes, void* stream) {
+  if (!after_score_dev || !after_id_dev) {
+    rf_set_error("rf_search_exhaustive_after: null bound arrays");
+    return RF_ERR_INVALID;
+  }
+  return exhaustive_impl("rf_search_exhaustive_after", ix, q_dev, B, k, id_base, scores_dev, ids_dev,
+                         exact_dev, after_score_dev, after_id_dev, workspace_dev, workspace_bytes, stream);
 }
 
 extern "C" int rf_merge_shards(const double* exact_dev, const int64_t* ids_dev, int W, int B, int k,

@@ -422,7 +422,8 @@ __device__ void exlist_update(ExList* L, double* t_s, int64_t* t_r, int* t_n, in
 
 __global__ void __launch_bounds__(EX_THREADS) k_exhaustive_scan(
     const _Float16* __restrict__ q, int dim, int KS, const uint4* __restrict__ tiles, int64_t n_rows,
-    int k, double* __restrict__ out_s, int64_t* __restrict__ out_r) {
+    int k, double* __restrict__ out_s, int64_t* __restrict__ out_r,
+    const double* __restrict__ after_s, const int64_t* __restrict__ after_r, int64_t id_base) {
   __shared__ ExList L;
   __shared__ double t_s[RF_MAX_K + EX_THREADS];
   __shared__ int64_t t_r[RF_MAX_K + EX_THREADS];
@@ -432,11 +433,16 @@ __global__ void __launch_bounds__(EX_THREADS) k_exhaustive_scan(
   if (tid == 0) L.n = 0;
   __syncthreads();
   const _Float16* qrow = q + (size_t)qi * dim;
+  // paging: only rows ranked strictly AFTER (after_s, after_r) are eligible
+  const bool paged = after_s != nullptr;
+  const double bs = paged ? after_s[qi] : 0.0;
+  const int64_t br = paged ? after_r[qi] - id_base : 0;
   const int64_t step = (int64_t)gridDim.x * EX_THREADS;
   for (int64_t base = (int64_t)blockIdx.x * EX_THREADS; base < n_rows; base += step) {
     const int64_t row = base + tid;
-    const bool valid = row < n_rows;
+    bool valid = row < n_rows;
     const double s = valid ? exact_dot(qrow, tiles, row, KS) : 0.0;
+    if (paged) valid = valid && ranks_before(bs, br, s, row);
     exlist_update(&L, t_s, t_r, &t_n, k, s, row, valid, tid);
   }
   const size_t o = ((size_t)qi * gridDim.x + blockIdx.x) * RF_MAX_K;
@@ -551,12 +557,12 @@ int rf_launch_merge(const rf_index* ix, const void* q, int B, int k, int64_t id_
 
 int rf_launch_exhaustive(const rf_index* ix, const void* q, int B, int k, int64_t id_base,
                          const rf_workspace& ws, float* scores, int64_t* ids, double* exact,
-                         hipStream_t st) {
+                         const double* after_s, const int64_t* after_r, hipStream_t st) {
   int64_t need = (ix->size + EX_THREADS - 1) / EX_THREADS;
   int lists = (int)(need < RF_EX_WGS ? (need < 1 ? 1 : need) : RF_EX_WGS);
   hipLaunchKernelGGL(k_exhaustive_scan, dim3(lists, B), dim3(EX_THREADS), 0, st,
                      (const _Float16*)q, ix->dim, ix->KS, ix->tiles, ix->size, k, ws.ex_score,
-                     ws.ex_row);
+                     ws.ex_row, after_s, after_r, id_base);
   hipLaunchKernelGGL(k_exhaustive_final, dim3(B), dim3(EX_THREADS), 0, st, ws.ex_score, ws.ex_row,
                      lists, k, id_base, scores, ids, exact);
   RF_HIP(hipGetLastError());

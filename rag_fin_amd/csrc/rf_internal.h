@@ -102,7 +102,7 @@ int rf_launch_merge(const rf_index* ix, const void* q, int B, int k, int64_t id_
                     uint32_t* flags, hipStream_t st);
 int rf_launch_exhaustive(const rf_index* ix, const void* q, int B, int k, int64_t id_base,
                          const rf_workspace& ws, float* scores, int64_t* ids, double* exact,
-                         hipStream_t st);
+                         const double* after_s, const int64_t* after_r, hipStream_t st);
 int rf_launch_merge_shards(const double* exact, const int64_t* ids, int W, int B, int k,
                            float* scores_out, int64_t* ids_out, hipStream_t st);
 

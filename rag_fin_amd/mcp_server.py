@@ -39,10 +39,26 @@ def health_check():
     return get_rag().health_check()
 
 
+_batcher = None
+
+
+def _searcher():
+    """RAGFIN_MICROBATCH_MS > 0: coalesce concurrent tool calls into one GPU batch
+    (rag_fin_amd.batching); default: one search per call, like the reference."""
+    global _batcher
+    ms = float(os.getenv("RAGFIN_MICROBATCH_MS", "0") or 0)
+    if ms <= 0:
+        return get_rag()
+    if _batcher is None or _batcher.rag is not get_rag():
+        from .batching import MicroBatcher
+        _batcher = MicroBatcher(get_rag(), max_batch=64, max_wait_ms=ms)
+    return _batcher
+
+
 def search_vectors(query: str, top_k: int = 3):
     """Semantic search in vector store"""
     try:
-        contexts = get_rag().search(query, top_k)
+        contexts = _searcher().search(query, top_k)
         return {"status": "success", "query": query, "results": contexts,
                 "result_count": len(contexts)}
     except Exception as e:

@@ -189,6 +189,40 @@ class GpuIndex:
                 _lib.current_stream_ptr()))
         return scores, ids, exact
 
+    def search_large(self, q16, k: int, id_base: int = 0):
+        """Limits above RF_MAX_K: the first page through the fused path, further pages
+        of RF_MAX_K through rf_search_exhaustive_after (each page = the hits ranked
+        strictly after the previous page's last hit).  Returns (scores, ids) [B, k]."""
+        torch = _torch()
+        q16 = q16.to(self.device).contiguous()
+        B = q16.shape[0]
+        page = _lib.RF_MAX_K
+        s0, i0, e0 = self.search(q16, page, id_base, want_exact=True)
+        scores, ids = [s0], [i0]
+        last_s, last_i = e0[:, -1].contiguous(), i0[:, -1].contiguous()
+        got = page
+        while got < k and bool((last_i >= 0).any()):
+            s = torch.empty((B, page), dtype=torch.float32, device=self.device)
+            i = torch.empty((B, page), dtype=torch.int64, device=self.device)
+            e = torch.empty((B, page), dtype=torch.float64, device=self.device)
+            # exhausted queries keep a bound nothing can follow
+            bs = torch.where(last_i >= 0, last_s, torch.full_like(last_s, float("-inf")))
+            bi = torch.where(last_i >= 0, last_i, torch.full_like(last_i, 2 ** 62))
+            with self._lock, torch.cuda.device(self.device):
+                _lib.check(self.lib.rf_search_exhaustive_after(
+                    self.handle, c_void_p(q16.data_ptr()), B, page, id_base, c_void_p(bs.data_ptr()),
+                    c_void_p(bi.data_ptr()), c_void_p(s.data_ptr()), c_void_p(i.data_ptr()),
+                    c_void_p(e.data_ptr()), c_void_p(self.workspace.data_ptr()), self.workspace_bytes,
+                    _lib.current_stream_ptr()))
+            scores.append(s)
+            ids.append(i)
+            last_s, last_i = e[:, -1].contiguous(), i[:, -1].contiguous()
+            got += page
+        if got < k:   # corpus exhausted before k hits: pad like rf_search does
+            scores.append(torch.full((B, k - got), float("-inf"), dtype=torch.float32, device=self.device))
+            ids.append(torch.full((B, k - got), -1, dtype=torch.int64, device=self.device))
+        return torch.cat(scores, 1)[:, :k].contiguous(), torch.cat(ids, 1)[:, :k].contiguous()
+
     def search(self, q16, k: int, id_base: int = 0, want_exact: bool = False):
         """rf_search, then re-run any query the fused path could not prove exact
         (flags != 0) through the exhaustive fp64 kernel.  Serialised: the index
@@ -352,11 +386,11 @@ class CorpusStore:
         """(scores f32 [B,k'], rows i64 [B,k']) as host numpy, k' = min(limit, N)."""
         if limit < 1:
             raise ValueError("limit must be >= 1")
-        if limit > _lib.RF_MAX_K:
-            raise _lib.RagfinError(-2, f"limit {limit} > {_lib.RF_MAX_K} is not served by the fused "
-                                       "scan yet")
         q16 = self._prepare_queries(data)
-        scores, rows, _ = self.index.search(q16, limit)
+        if limit > _lib.RF_MAX_K:
+            scores, rows = self.index.search_large(q16, limit)   # paged, exhaustive beyond 64
+        else:
+            scores, rows, _ = self.index.search(q16, limit)
         kk = min(limit, self.num_entities)
         return scores[:, :kk].cpu().numpy(), rows[:, :kk].cpu().numpy()
 

@@ -241,3 +241,20 @@ def test_wide_sweep_equals_narrow_sweeps(gpu_device, monkeypatch):
     torch.cuda.synchronize()
     assert int(f1.abs().sum()) == 0
     assert torch.equal(i1, torch.cat([p[1] for p in parts])) and torch.equal(e1, torch.cat([p[2] for p in parts]))
+
+
+@pytest.mark.parametrize("n,k", [(5_000, 1000), (30_000, 200), (100, 1000)])
+def test_limits_above_64_are_paged_exactly(gpu_device, n, k):
+    """graph_cons.hybrid_query_simple searches with limit=1000 (graph_cons.py:275-281):
+    pages of 64 ranked strictly after the previous page's last hit must reproduce the
+    oracle's full ranking, across exact-duplicate ties that straddle page boundaries."""
+    import torch
+    c = osearch.synth_unit_rows(n, 384, 91)
+    c[60:70] = c[5]                              # a tie group inside / across the first page edge
+    q16 = osearch.synth_unit_rows(3, 384, 92)
+    q16[0] = c[5]
+    ix = make_index(c, gpu_device)
+    scores, ids = ix.search_large(torch.from_numpy(q16).to(gpu_device), k)
+    os_, oi = c_oracle.search(q16, c, k)
+    assert np.array_equal(ids.cpu().numpy(), oi)
+    assert np.array_equal(scores.cpu().numpy(), os_.astype(np.float32))

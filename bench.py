@@ -11,7 +11,9 @@ the HBM-resident corpus -> ranked (score, row id) lists in HBM.
 
 N > 1: the corpus is row-sharded (1M rows per GPU, weak scaling), the query batch
 is replicated, and each step ends with ONE RCCL all-gather of the per-shard top-k
-plus a merge (rag_fin_amd/sharded.py).  `value` stays "queries/sec of the whole
+plus a merge (rag_fin_amd/sharded.py); batches in flight work the same way (the
+all-gathers of the lanes share one communicator and are issued in the same order
+on every rank).  `value` stays "queries/sec of the whole
 job" -- the job answers the same 64 queries per step against an N-times larger
 corpus -- so under weak scaling the ideal is a flat value; `rows_per_s` in the
 JSON carries the aggregate scan rate that grows with N.
@@ -109,7 +111,7 @@ def main():
     searcher = ShardedSearcher(HipShardBackend(index), row_base=rank * rows) if world > 1 else None
     # `streams` batches in flight: each has its own HIP stream, workspace and output
     # buffers; the corpus index is immutable and shared.  Step i runs on lane i % lanes.
-    max_lanes = max(1, args.streams) if searcher is None else 1
+    max_lanes = max(1, args.streams)
     lanes = []
     for i in range(max_lanes):
         lanes.append(dict(
@@ -132,13 +134,14 @@ def main():
         res = [None]
 
         def step():
-            if searcher is not None:
-                res[0] = searcher.search(q, k)
-                return
             lane = lanes[counter[0] % n_lanes]
             counter[0] += 1
             with torch.cuda.stream(lane["stream"]):
-                index.search_raw(q, k, want_exact=True, out=lane["out"], workspace=lane["ws"])
+                if searcher is not None:
+                    lane["res"] = searcher.search(q, k, workspace=lane["ws"])
+                    res[0] = lane["res"]
+                else:
+                    index.search_raw(q, k, want_exact=True, out=lane["out"], workspace=lane["ws"])
         for _ in range(args.warmup):
             step()
         barrier()
@@ -167,7 +170,9 @@ def main():
         same = all(torch.equal(l["out"][1], out[1]) and torch.equal(l["out"][2], out[2]) for l in lanes)
         flags_clean = flags_clean and same   # every lane answered the same queries identically
     else:
-        flags_clean = int(res[2].abs().sum().item()) == 0
+        done = [l["res"] for l in lanes if l.get("res") is not None]
+        flags_clean = all(int(r[2].abs().sum().item()) == 0 for r in done) and \
+            all(torch.equal(r[1], done[0][1]) for r in done)
 
     result = None
     if rank == 0:

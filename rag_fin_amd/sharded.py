@@ -29,8 +29,9 @@ class HipShardBackend:
         self.device = index.device
         self.lib = index.lib
 
-    def local_topk(self, q16, k: int, row_base: int):
-        scores, ids, exact, flags = self.index.search_raw(q16, k, id_base=row_base, want_exact=True)
+    def local_topk(self, q16, k: int, row_base: int, workspace=None):
+        scores, ids, exact, flags = self.index.search_raw(q16, k, id_base=row_base, want_exact=True,
+                                                          workspace=workspace)
         return exact, ids, flags
 
     def merge(self, exact_all, ids_all, k: int):
@@ -64,12 +65,19 @@ class ShardedSearcher:
         start = rank * base + min(rank, extra)
         return start, start + base + (1 if rank < extra else 0)
 
-    def search(self, q16, k: int):
+    def search(self, q16, k: int, workspace=None):
         """Returns (scores f32 [B,k], global ids i64 [B,k], flags).  flags are the
         local scan's per-query flags (non-zero -> caller re-runs those queries
-        through the exhaustive path before trusting the merge)."""
+        through the exhaustive path before trusting the merge).
+
+        Several batches may be in flight: call from different HIP streams with one
+        `workspace` each (GpuIndex.new_workspace()); every rank must issue its searches
+        in the same order, because the all-gathers share one communicator."""
         import torch
-        exact, ids, flags = self.backend.local_topk(q16, k, self.row_base)
+        if workspace is None:
+            exact, ids, flags = self.backend.local_topk(q16, k, self.row_base)
+        else:
+            exact, ids, flags = self.backend.local_topk(q16, k, self.row_base, workspace)
         if self.world == 1:
             scores, gids = self.backend.merge(exact.unsqueeze(0).contiguous(),
                                               ids.unsqueeze(0).contiguous(), k)

@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
     int64_t id_base, const uint32_t* __restrict__ cand_cnt, const uint2* __restrict__ cand,
     uint32_t cap, const float* __restrict__ eps_in, float* __restrict__ scores,
     int64_t* __restrict__ ids, double* __restrict__ exact, uint32_t* __restrict__ flags,
-    uint32_t* __restrict__ cand_cnt_rw, uint32_t* __restrict__ gmax, uint32_t* __restrict__ bar) {
+    uint32_t* __restrict__ cand_cnt_rw, uint32_t* __restrict__ gmax, uint32_t* __restrict__ bar,
+    uint32_t n_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned long long* skeys = (unsigned long long*)lds;                       // [1024]
   unsigned long long* wtop = skeys + MERGE_RANK_MAX;                          // [4][RF_MAX_K]
@@ -193,6 +194,7 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  bool bad_row = false;
   // candidate lists of this query: RF_CAND_SHARDS lists of up to `cap` entries;
   // global candidate index g -> (list s, entry g - off[s])
   uint32_t off[RF_CAND_SHARDS + 1];
@@ -214,7 +216,15 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
     int s = 0;
 #pragma unroll
     for (int t = 1; t < RF_CAND_SHARDS; ++t) s += g >= off[t] ? 1 : 0;
-    return lists[(size_t)s * cap + (g - off[s])];
+    uint2 e = lists[(size_t)s * cap + (g - off[s])];
+    // a row id past the corpus can only come from a workspace whose control block was
+    // not clean; never let it reach the row gather -- make it the worst candidate and flag
+    if (e.x >= n_rows) {
+      e.x = 0u;
+      e.y = 0xFF800000u;  // -inf
+      bad_row = true;
+    }
+    return e;
   };
   const float eps2 = 2.f * eps_in[qi];
   if (tid == 0) {
@@ -369,6 +379,7 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
     ids[o] = -1;
     if (exact) exact[o] = -INFINITY;
   }
+  if (flags && __syncthreads_or(bad_row ? 1 : 0)) fl |= RF_FLAG_CAND_OVERFLOW;
   if (tid == 0 && flags) flags[qi] = fl;
   // leave the control block zero for the next search on this workspace (every
   // thread of this workgroup read its counters before the barriers above)
@@ -550,7 +561,8 @@ int rf_launch_merge(const rf_index* ix, const void* q, int B, int k, int64_t id_
   }
   hipLaunchKernelGGL(k_merge, dim3(B), dim3(MERGE_THREADS), lds, st, (const _Float16*)q, ix->dim,
                      ix->KS, ix->tiles, k, id_base, ws.cand_cnt, ws.cand, (uint32_t)RF_SHARD_CAP,
-                     ws.eps, scores, ids, exact, flags, ws.cand_cnt, ws.gmax, ws.bar);
+                     ws.eps, scores, ids, exact, flags, ws.cand_cnt, ws.gmax, ws.bar,
+                     (uint32_t)ix->size);
   RF_HIP(hipGetLastError());
   return RF_OK;
 }

@@ -336,7 +336,7 @@ int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_wo
   const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
   const int WAVES = waves_per_wg(KS);
   const int wgs_env = tuning().emit_wgs_per_cu;
-  int grid = 256 * (wgs_env > 0 ? wgs_env : wgs_per_cu(KS));
+  int grid = ix->num_cus * (wgs_env > 0 ? wgs_env : wgs_per_cu(KS));
   const uint32_t need = (nblk + WAVES - 1) / WAVES;
   if ((uint32_t)grid > need) grid = (int)need;
   if (grid < 1) grid = 1;

@@ -70,7 +70,7 @@ class GpuIndex:
                                                 self.device.index))
             self.handle = handle
             ws = self.lib.rf_search_workspace_bytes(self.handle)
-            self.workspace = torch.empty(ws, dtype=torch.uint8, device=self.device)
+            self.workspace = torch.zeros(ws, dtype=torch.uint8, device=self.device)
             self.workspace_bytes = ws
         self._lock = threading.Lock()
 
@@ -129,7 +129,7 @@ class GpuIndex:
         """An extra search workspace: one per batch in flight when several streams
         search the same (immutable) index concurrently."""
         torch = _torch()
-        return torch.empty(self.workspace_bytes, dtype=torch.uint8, device=self.device)
+        return torch.zeros(self.workspace_bytes, dtype=torch.uint8, device=self.device)
 
     def search_raw(self, q16, k: int, id_base: int = 0, want_exact: bool = False, out=None,
                    workspace=None):

@@ -44,7 +44,7 @@ struct rf_encoder {
 
 static bool cfg_supported(const rf_encoder_config* c) {
   return c && c->hidden == HID && c->heads > 0 && c->hidden / c->heads == HEAD_DIM &&
-         c->hidden % c->heads == 0 && c->intermediate > 0 && c->intermediate % 384 == 0 &&
+         c->hidden % c->heads == 0 && c->intermediate == 4 * HID &&
          c->layers > 0 && c->vocab_size > 0 && c->max_position > 0 && c->type_vocab > 0;
 }
 
@@ -67,7 +67,7 @@ extern "C" int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cf
   *out = nullptr;
   if (!cfg_supported(cfg)) {
     rf_set_error("rf_encoder_create: unsupported config (need hidden 384, head_dim 32, "
-                 "intermediate %% 384 == 0); got hidden=%d heads=%d intermediate=%d",
+                 "intermediate 1536); got hidden=%d heads=%d intermediate=%d",
                  cfg->hidden, cfg->heads, cfg->intermediate);
     return RF_ERR_UNSUPPORTED;
   }
@@ -265,7 +265,12 @@ __device__ __forceinline__ float gelu_erf(float y) {
 // SLOWER here (12-24 MFMAs between barriers cannot hide them at this occupancy).
 // The accumulator holds the TOKEN on the lane and FEATURES in registers: 4 consecutive
 // features per register quad -> 8-byte stores, and lane-local LayerNorm partial sums.
-template <int EPI, int NTB>   // NTB = 32-token blocks per workgroup
+// The k-loop is latency-bound unless several k-steps are in flight (a k-step is only
+// 3*NTB MFMAs = 96-192 matrix cycles against ~1500 cycles to L2): both operands run
+// through a 4-deep REGISTER RING -- fragment set d is re-armed with k-step kk+4 right
+// after k-step kk has consumed it, with unconditional loads so hipcc can count them
+// (20 KB in flight per wave).  KS = K/16 is a template parameter (24 or 96).
+template <int EPI, int NTB, int KS>   // NTB = 32-token blocks per workgroup
 __global__ void __launch_bounds__(256) k_linear(
     const _Float16* __restrict__ X, int K, const uint4* __restrict__ Wt,
     const _Float16* __restrict__ bias, _Float16* __restrict__ out, int ldo,
@@ -280,7 +285,6 @@ __global__ void __launch_bounds__(256) k_linear(
   const int t0 = blockIdx.x * LIN_TOK;
   const int M = *m_ptr;
   if (t0 >= M) return;  // whole workgroup: no barrier is skipped by a subset
-  const int KS = K / 16;
   const int fgroup = blockIdx.y * 384 + wave * 96;  // first feature of this wave
   const uint4* wbase = Wt + (size_t)(fgroup / 32) * KS * 64 + lane;
 
@@ -293,19 +297,40 @@ __global__ void __launch_bounds__(256) k_linear(
       for (int i = 0; i < 16; ++i) acc[tb][fb][i] = 0.f;
 
   {
+    constexpr int D = 4;
+    static_assert(KS % D == 0, "ring depth must divide the k-steps");
     const _Float16* xrow = X + (size_t)(t0 + c) * K + h * 8;
-    for (int kk = 0; kk < KS; ++kk) {
-      half8 bfr[NTB];
+    half8 xr[D][NTB];
+    uint4 wr[D][3];
+    auto arm = [&](int d, int kk) {
 #pragma unroll
-      for (int tb = 0; tb < NTB; ++tb) bfr[tb] = *(const half8*)(xrow + (size_t)(32 * tb) * K + kk * 16);
+      for (int tb = 0; tb < NTB; ++tb) xr[d][tb] = *(const half8*)(xrow + (size_t)(32 * tb) * K + kk * 16);
 #pragma unroll
-      for (int fb = 0; fb < 3; ++fb) {
-        const half8 a = __builtin_bit_cast(half8, wbase[((size_t)fb * KS + kk) * 64]);
+      for (int fb = 0; fb < 3; ++fb) wr[d][fb] = wbase[((size_t)fb * KS + kk) * 64];
+    };
+    auto consume = [&](int d) {
+#pragma unroll
+      for (int fb = 0; fb < 3; ++fb)
 #pragma unroll
         for (int tb = 0; tb < NTB; ++tb)
-          acc[tb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfr[tb], acc[tb][fb], 0, 0, 0);
+          acc[tb][fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wr[d][fb]),
+                                                               xr[d][tb], acc[tb][fb], 0, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) arm(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kk0 = 0; kk0 < KS - D; kk0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        consume(d);
+        arm(d, kk0 + d + D);
+        // pin the re-arm here: left free, hipcc sinks the loads to just before their
+        // use four k-steps later (98 VGPRs, nothing in flight, no speed-up)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d) consume(d);
   }
 
   // acc[tb][fb][4 g + j] = Y[t0 + 32 tb + c][fgroup + 32 fb + 8 g + 4 h + j]
@@ -616,8 +641,12 @@ static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Floa
                           const _Float16* g, const _Float16* b, float eps, hipStream_t st) {
   constexpr int NTB = EPI == EPI_BIAS_RES_LN ? 1 : 2;
   const int tiles = (tokens + 32 * NTB - 1) / (32 * NTB);
-  hipLaunchKernelGGL((k_linear<EPI, NTB>), dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out,
-                     N, m_ptr, res, g, b, eps);
+  if (K == 384)
+    hipLaunchKernelGGL((k_linear<EPI, NTB, 24>), dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out,
+                       N, m_ptr, res, g, b, eps);
+  else   // K == 1536 (checked by rf_encoder_create: intermediate == 4 * hidden is the only other K)
+    hipLaunchKernelGGL((k_linear<EPI, NTB, 96>), dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out,
+                       N, m_ptr, res, g, b, eps);
 }
 
 extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev,

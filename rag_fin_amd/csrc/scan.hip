@@ -312,8 +312,9 @@ int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_
   if (n_work < lo) n_work = lo;
   if (n_work > hi) n_work = hi;
   if (n_work > nblk) n_work = nblk;
-  const uint32_t per_wg = (uint32_t)WAVES * (n_work >= (uint32_t)RF_SAMPLE_WGS * WAVES ? SAMPLE_BPW : 1);
-  int grid = (int)((n_work + per_wg - 1) / per_wg);
+  // as many workgroups as there are waves' worth of blocks, capped at one per partition
+  // slot; waves take blocks round-robin, so the load is balanced for any n_work
+  int grid = (int)((n_work + WAVES - 1) / WAVES);
   if (grid > RF_SAMPLE_WGS) grid = RF_SAMPLE_WGS;
   if (grid < 1) grid = 1;
   const uint32_t bstride = nblk / n_work;  // >= 1

@@ -5,8 +5,8 @@
 //
 // Data layout
 //   * tokens are PACKED: only the lens[b] valid tokens of each sequence occupy
-//     rows of the activation matrices ([M, 384] fp16 row-major, M = sum lens), so
-//     padding costs nothing and needs no attention mask;
+//     rows of the activation matrices (M = sum lens), so padding costs nothing and
+//     needs no attention mask; the matrices themselves are fragment-tiled (toff());
 //   * every Linear weight [out, in] is stored once in the same 32-row x 16-k MFMA
 //     fragment tiling as the corpus (rf_internal.h): one 1-KiB wave load = one
 //     A operand of v_mfma_f32_32x32x16_f16.
@@ -31,6 +31,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define HID 384
 #define HEAD_DIM 32
+
+// Activations live in the same fragment tiling as the corpus and the weights:
+// [token block of 32][k-step = feature/16][lane = 32*((feature/8)&1) + token%32][8 halfs].
+// A 32-token x 16-feature fragment is 1 KiB contiguous, so the GEMMs read their B
+// operands with one coalesced wave load, and an epilogue's 4-consecutive-feature
+// stores of a wave fill 512 contiguous bytes.  (Row-major activations made every
+// B-fragment load touch 32 different cache lines: the GEMMs were TA-bound at ~17 %
+// of the matrix peak.)  toff() = offset in halfs of (token t, feature f); KSf = width/16.
+__device__ __forceinline__ size_t toff(int t, int f, int KSf) {
+  return (((size_t)(t >> 5) * KSf + (f >> 4)) * 64 + (size_t)(((f >> 3) & 1) * 32 + (t & 31))) * 8 + (f & 7);
+}
 
 struct rf_encoder {
   rf_encoder_config cfg;
@@ -230,7 +241,7 @@ __global__ void __launch_bounds__(256) k_embed_ln(
       half8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (_Float16)((v[j] - mu) * rstd * (float)gg[j] + (float)bb[j]);
-      *(half8*)(out + ((size_t)tok_off[bi] + p) * HID + lane * 8) = o;
+      *(half8*)(out + toff(tok_off[bi] + p, lane * 8, HID / 16)) = o;
     }
   }
 }
@@ -299,12 +310,12 @@ __global__ void __launch_bounds__(256) k_linear(
   {
     constexpr int D = 4;
     static_assert(KS % D == 0, "ring depth must divide the k-steps");
-    const _Float16* xrow = X + (size_t)(t0 + c) * K + h * 8;
+    const _Float16* xfrag = X + ((size_t)(t0 >> 5) * KS * 64 + lane) * 8;   // fragment (block, kk) = 1 KiB
     half8 xr[D][NTB];
     uint4 wr[D][3];
     auto arm = [&](int d, int kk) {
 #pragma unroll
-      for (int tb = 0; tb < NTB; ++tb) xr[d][tb] = *(const half8*)(xrow + (size_t)(32 * tb) * K + kk * 16);
+      for (int tb = 0; tb < NTB; ++tb) xr[d][tb] = *(const half8*)(xfrag + ((size_t)tb * KS + kk) * 512);
 #pragma unroll
       for (int fb = 0; fb < 3; ++fb) wr[d][fb] = wbase[((size_t)fb * KS + kk) * 64];
     };
@@ -351,7 +362,7 @@ __global__ void __launch_bounds__(256) k_linear(
           v[fb][4 * g + j] = y;
         }
         if (EPI == EPI_BIAS_RES_LN) {
-          const half4 rv = *(const half4*)(res + (size_t)token * HID + f);
+          const half4 rv = *(const half4*)(res + toff(token, f, HID / 16));
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[fb][4 * g + j] += (float)rv[j];
         }
@@ -398,7 +409,7 @@ __global__ void __launch_bounds__(256) k_linear(
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[fb][4 * g + j];
           }
-          *(half4*)(out + (size_t)token * ldo + f) = o;
+          *(half4*)(out + toff(token, f, ldo / 16)) = o;
         }
     }
   }
@@ -438,9 +449,8 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const _Float16* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) { kv[e] = (_Float16)0.f; vv[e] = (_Float16)0.f; }
     if (row < n) {
-      const _Float16* src = qkv + (size_t)(r0 + row) * (3 * HID) + head * HEAD_DIM + part * 8;
-      kv = *(const half8*)(src + HID);
-      vv = *(const half8*)(src + 2 * HID);
+      kv = *(const half8*)(qkv + toff(r0 + row, HID + head * HEAD_DIM + part * 8, 3 * HID / 16));
+      vv = *(const half8*)(qkv + toff(r0 + row, 2 * HID + head * HEAD_DIM + part * 8, 3 * HID / 16));
     }
     *(half8*)(ks + row * 40 + part * 8) = kv;
 #pragma unroll
@@ -456,7 +466,7 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const _Float16* __restri
 #pragma unroll
       for (int e = 0; e < 8; ++e) qf[s][e] = (_Float16)0.f;
       if (q0 + c < n)
-        qf[s] = *(const half8*)(qkv + (size_t)(r0 + q0 + c) * (3 * HID) + head * HEAD_DIM + 16 * s + 8 * h);
+        qf[s] = *(const half8*)(qkv + toff(r0 + q0 + c, head * HEAD_DIM + 16 * s + 8 * h, 3 * HID / 16));
     }
     f32x16 sc[ATT_MAX_KB];
     float m = -INFINITY;
@@ -518,13 +528,12 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const _Float16* __restri
     }
     if (q0 + c < n) {
       const float inv = 1.f / l;
-      _Float16* dst = ctx + (size_t)(r0 + q0 + c) * HID + head * HEAD_DIM;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         half4 t;
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = (_Float16)(o[4 * g + j] * inv);
-        *(half4*)(dst + 8 * g + 4 * h) = t;
+        *(half4*)(ctx + toff(r0 + q0 + c, head * HEAD_DIM + 8 * g + 4 * h, HID / 16)) = t;
       }
     }
   }
@@ -545,18 +554,16 @@ __global__ void __launch_bounds__(256) k_attention(const _Float16* __restrict__ 
   const int tid = threadIdx.x;
   for (int i = tid; i < n * 4; i += 256) {
     const int row = i >> 2, part = i & 3;
-    const _Float16* src = qkv + (size_t)(r0 + row) * (3 * HID) + head * HEAD_DIM + part * 8;
-    ks[i] = *(const half8*)(src + HID);
-    vs[i] = *(const half8*)(src + 2 * HID);
+    ks[i] = *(const half8*)(qkv + toff(r0 + row, HID + head * HEAD_DIM + part * 8, 3 * HID / 16));
+    vs[i] = *(const half8*)(qkv + toff(r0 + row, 2 * HID + head * HEAD_DIM + part * 8, 3 * HID / 16));
   }
   __syncthreads();
   const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
   for (int qi = tid; qi < n; qi += 256) {
     float q[HEAD_DIM];
-    const _Float16* qsrc = qkv + (size_t)(r0 + qi) * (3 * HID) + head * HEAD_DIM;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const half8 t = *(const half8*)(qsrc + p * 8);
+      const half8 t = *(const half8*)(qkv + toff(r0 + qi, head * HEAD_DIM + p * 8, 3 * HID / 16));
 #pragma unroll
       for (int j = 0; j < 8; ++j) q[p * 8 + j] = (float)t[j] * scale;
     }
@@ -585,13 +592,12 @@ __global__ void __launch_bounds__(256) k_attention(const _Float16* __restrict__ 
       m = mn;
     }
     const float inv = 1.f / l;
-    _Float16* dst = ctx + (size_t)(r0 + qi) * HID + head * HEAD_DIM;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       half8 t;
 #pragma unroll
       for (int e = 0; e < 8; ++e) t[e] = (_Float16)(o[p * 8 + e] * inv);
-      *(half8*)(dst + p * 8) = t;
+      *(half8*)(ctx + toff(r0 + qi, head * HEAD_DIM + p * 8, HID / 16)) = t;
     }
   }
 }
@@ -609,7 +615,7 @@ __global__ void __launch_bounds__(192) k_pool_norm(const _Float16* __restrict__ 
   const int n = tok_off[b + 1] - r0;
   float a0 = 0.f, a1 = 0.f;
   for (int r = 0; r < n; ++r) {
-    const _Float16* row = x + (size_t)(r0 + r) * HID + tid * 2;
+    const _Float16* row = x + toff(r0 + r, tid * 2, HID / 16);
     a0 += (float)row[0];
     a1 += (float)row[1];
   }

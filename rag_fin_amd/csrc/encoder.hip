@@ -645,7 +645,7 @@ template <int EPI>
 static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Float16* bias,
                           _Float16* out, int N, int tokens, const int32_t* m_ptr, const _Float16* res,
                           const _Float16* g, const _Float16* b, float eps, hipStream_t st) {
-  constexpr int NTB = EPI == EPI_BIAS_RES_LN ? 1 : 2;
+  constexpr int NTB = 2;
   const int tiles = (tokens + 32 * NTB - 1) / (32 * NTB);
   if (K == 384)
     hipLaunchKernelGGL((k_linear<EPI, NTB, 24>), dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out,

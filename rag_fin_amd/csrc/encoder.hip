@@ -281,6 +281,10 @@ __device__ __forceinline__ float gelu_erf(float y) {
 // through a 4-deep REGISTER RING -- fragment set d is re-armed with k-step kk+4 right
 // after k-step kk has consumed it, with unconditional loads so hipcc can count them
 // (20 KB in flight per wave).  KS = K/16 is a template parameter (24 or 96).
+// Copying the workgroup's X tile to LDS once (the four waves need the same B
+// fragments) was measured SLOWER in three forms (row-major + barrier per stage, whole
+// tile up front, tiled copy + this W ring: QKV 41 -> 51 us, FFN1 66 -> 80 us): the
+// redundant per-wave fragment loads are L1 hits and cost less than the LDS round trip.
 template <int EPI, int NTB, int KS>   // NTB = 32-token blocks per workgroup
 __global__ void __launch_bounds__(256) k_linear(
     const _Float16* __restrict__ X, int K, const uint4* __restrict__ Wt,

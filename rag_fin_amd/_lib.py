@@ -93,6 +93,13 @@ def load_library() -> ctypes.CDLL:
     path = library_path()
     if not os.path.exists(path):
         _build.build_lib()  # raises if hipcc is missing -- no fallback
+    # torch ships its own libamdhip64; load it FIRST so that this library binds to the
+    # same HIP runtime instance (loaded the other way round, the two runtimes disagree
+    # about device visibility: rf_device_check saw "no HIP device" on a GPU box)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

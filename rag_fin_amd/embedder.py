@@ -218,17 +218,3 @@ class Embedder:
         arr = emb.float().cpu().numpy()
         return arr[0] if single else arr
 
-
-def smoke(device) -> None:
-    """Tiny encoder forward checked against the oracle (called by __graft_entry__.smoke)."""
-    from oracle import encoder as oenc
-    cfg = dict(MINILM_L6, layers=2, vocab_size=1000, max_position=64)
-    w = oenc.random_weights(cfg, 3)
-    emb = Embedder(w, cfg, device=device)
-    rng = np.random.default_rng(0)
-    lens = np.array([17, 5, 32, 1], dtype=np.int32)
-    ids = rng.integers(1, 1000, (4, 32)).astype(np.int32)
-    got = emb.encode_ids(ids, lens).float().cpu().numpy()
-    want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids, lens)
-    err = np.abs(got - want).max()
-    assert err < 5e-3, f"encoder smoke: max abs err {err}"

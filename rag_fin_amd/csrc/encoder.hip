@@ -431,38 +431,49 @@ __global__ void __launch_bounds__(256) k_linear(
 //                 rows (stride T+4 halfs: conflict-free b64 reads) supply the A operand in
 //                 the same key order.
 #define ATT_MAX_KB 8
-__global__ void __launch_bounds__(256) k_attention_mfma(const _Float16* __restrict__ qkv,
+#define ATT_HEADS 2   // heads per workgroup (12 heads -> grid.y = 6)
+__global__ void __launch_bounds__(256, 2) k_attention_mfma(const _Float16* __restrict__ qkv,
                                                         const int32_t* __restrict__ tok_off,
                                                         _Float16* __restrict__ ctx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int b = blockIdx.x, head = blockIdx.y;
+  // a workgroup serves ATT_HEADS heads of one sequence: the (head, query block) items are
+  // dealt round-robin to the 4 waves (5 query blocks x 2 heads = 10 items -> 3 rounds
+  // instead of 2 x 2), and the fixed launch / staging latencies are paid once per pair
+  const int b = blockIdx.x, head0 = blockIdx.y * ATT_HEADS;
   const int r0 = tok_off[b];
   const int n = tok_off[b + 1] - r0;
   if (n <= 0) return;
   const int nkb = (n + 31) >> 5;
   const int tpad = nkb * 32;
-  _Float16* ks = (_Float16*)lds;                       // [tpad][40]
-  _Float16* vt = ks + (size_t)tpad * 40;               // [32][tpad + 4]
   const int vstride = tpad + 4;
+  const size_t head_lds = (size_t)tpad * 40 + (size_t)32 * vstride;    // halfs per head: K rows, then V^T
+  _Float16* lds_h = (_Float16*)lds;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
-  for (int i = tid; i < tpad * 4; i += 256) {
-    const int row = i >> 2, part = i & 3;
+  for (int i = tid; i < ATT_HEADS * tpad * 4; i += 256) {
+    const int hh = i / (tpad * 4), rem = i % (tpad * 4);
+    const int row = rem >> 2, part = rem & 3;
     half8 kv, vv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { kv[e] = (_Float16)0.f; vv[e] = (_Float16)0.f; }
     if (row < n) {
-      kv = *(const half8*)(qkv + toff(r0 + row, HID + head * HEAD_DIM + part * 8, 3 * HID / 16));
-      vv = *(const half8*)(qkv + toff(r0 + row, 2 * HID + head * HEAD_DIM + part * 8, 3 * HID / 16));
+      kv = *(const half8*)(qkv + toff(r0 + row, HID + (head0 + hh) * HEAD_DIM + part * 8, 3 * HID / 16));
+      vv = *(const half8*)(qkv + toff(r0 + row, 2 * HID + (head0 + hh) * HEAD_DIM + part * 8, 3 * HID / 16));
     }
-    *(half8*)(ks + row * 40 + part * 8) = kv;
+    _Float16* ks_w = lds_h + hh * head_lds;
+    _Float16* vt_w = ks_w + (size_t)tpad * 40;
+    *(half8*)(ks_w + row * 40 + part * 8) = kv;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) vt[(part * 8 + e) * vstride + row] = vv[e];
+    for (int e = 0; e < 8; ++e) vt_w[(part * 8 + e) * vstride + row] = vv[e];
   }
   __syncthreads();
   const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
-  for (int qb = wave; qb < nkb; qb += 4) {
+  for (int item = wave; item < ATT_HEADS * nkb; item += 4) {
+    const int head = head0 + item / nkb;
+    const int qb = item % nkb;
+    const _Float16* ks = lds_h + (item / nkb) * head_lds;     // [tpad][40]
+    const _Float16* vt = ks + (size_t)tpad * 40;             // [32][tpad + 4]
     const int q0 = qb * 32;
     half8 qf[2];
 #pragma unroll
@@ -485,24 +496,29 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const _Float16* __restri
           const half8 a = *(const half8*)(ks + (kb * 32 + c) * 40 + 16 * s + 8 * h);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], acc, 0, 0, 0);
         }
+        // raw scores stay in the accumulator; only the sequence's ragged LAST key block
+        // needs the key < n mask (wave-uniform branch), and the 1/sqrt(32) scale is folded
+        // into the exponent below: the softmax is VALU-bound, every op per element counts
+        if (kb == nkb - 1 && (n & 31) != 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-          const float v = key < n ? acc[i] * scale : -INFINITY;
-          acc[i] = v;
-          m = fmaxf(m, v);
+          for (int i = 0; i < 16; ++i)
+            if (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= n) acc[i] = -INFINITY;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[i]);
         sc[kb] = acc;
       }
     }
     m = fmaxf(m, __shfl_xor(m, 32));
     float l = 0.f;
+    const float c2 = scale * 1.4426950408889634f;   // exp(scale * (s - m)) = exp2(c2 * s - c2 * m)
+    const float mc = m * c2;
 #pragma unroll
     for (int kb = 0; kb < ATT_MAX_KB; ++kb) {
       if (kb < nkb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float pr = __expf(sc[kb][i] - m);
+          const float pr = __builtin_amdgcn_exp2f(fmaf(sc[kb][i], c2, -mc));
           sc[kb][i] = pr;
           l += pr;
         }
@@ -698,14 +714,19 @@ extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const 
                        (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
   }
   const size_t attn_lds = (size_t)T * 2 * HEAD_DIM * 2;
-  static size_t attn_attr = 0;
+  static size_t attn_attr = 0, mfma_attr = 0;
   if (attn_lds > attn_attr) {
     RF_HIP(hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)attn_lds));
     attn_attr = attn_lds;
   }
   const int tpad_max = (T + 31) / 32 * 32;
-  const size_t mfma_lds = (size_t)tpad_max * 80 + (size_t)32 * (tpad_max + 4) * 2;  // < 64 KB for T <= 256
+  const size_t mfma_lds = ATT_HEADS * ((size_t)tpad_max * 80 + (size_t)32 * (tpad_max + 4) * 2);  // 74 KB at T = 256
+  if (T <= 32 * ATT_MAX_KB && mfma_lds > mfma_attr) {
+    RF_HIP(hipFuncSetAttribute((const void*)k_attention_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)mfma_lds));
+    mfma_attr = mfma_lds;
+  }
   _Float16* x = ws.x;
   _Float16* y = ws.y;
   for (int l = 0; l < L; ++l) {
@@ -716,8 +737,8 @@ extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const 
     launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
                             3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, st);
     if (T <= 32 * ATT_MAX_KB)
-      hipLaunchKernelGGL(k_attention_mfma, dim3(B, c.heads), dim3(256), mfma_lds, st, ws.qkv, ws.tok_off,
-                         ws.ctx);
+      hipLaunchKernelGGL(k_attention_mfma, dim3(B, c.heads / ATT_HEADS), dim3(256), mfma_lds, st, ws.qkv,
+                         ws.tok_off, ws.ctx);
     else
       hipLaunchKernelGGL(k_attention, dim3(B, c.heads), dim3(256), attn_lds, st, ws.qkv, ws.tok_off,
                          ws.ctx);

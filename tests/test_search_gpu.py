@@ -258,3 +258,30 @@ def test_limits_above_64_are_paged_exactly(gpu_device, n, k):
     os_, oi = c_oracle.search(q16, c, k)
     assert np.array_equal(ids.cpu().numpy(), oi)
     assert np.array_equal(scores.cpu().numpy(), os_.astype(np.float32))
+
+
+def test_tuning_variants_stay_exact(gpu_device):
+    """Every kernel variant reachable through rf_set_tuning (ring depths, workgroups per
+    CU, sample size, the single-launch fused scan) returns the same bit-exact result."""
+    import torch
+    from rag_fin_amd import _lib
+    lib = _lib.load_library()
+    c = osearch.synth_unit_rows(90_000, 384, 41)
+    q16 = osearch.synth_unit_rows(64, 384, 42)
+    ix = make_index(c, gpu_device)
+    os_, oi = c_oracle.search(q16, c, 10)
+    q = torch.from_numpy(q16).to(gpu_device)
+    try:
+        for key, values in (("ring24", (6, 12, 24, 8)), ("emit_wgs_per_cu", (1, 3, 0)),
+                            ("sample_bpw", (1, 4, 2)), ("fused", (1, 0))):
+            for v in values:
+                _lib.check(lib.rf_set_tuning(key.encode(), v))
+                s, i, e, f = ix.search_raw(q, 10, want_exact=True)
+                torch.cuda.synchronize()
+                assert int(f.abs().sum()) == 0, (key, v)
+                assert np.array_equal(i.cpu().numpy(), oi), (key, v)
+                assert np.array_equal(e.cpu().numpy(), os_), (key, v)
+        assert lib.rf_set_tuning(b"ring24", 7) != 0 and lib.rf_set_tuning(b"nope", 1) != 0
+    finally:
+        for key, v in (("ring24", 8), ("emit_wgs_per_cu", 0), ("sample_bpw", 2), ("fused", 0)):
+            lib.rf_set_tuning(key.encode(), v)

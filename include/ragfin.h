@@ -126,6 +126,9 @@ int rf_merge_shards(const double* exact_dev, const int64_t* ids_dev, int W, int 
 /* Tuning hook (experiments / A-B runs in one process): key in {"ring24",
  * "emit_wgs_per_cu", "sample_bpw"}.  No reference counterpart. */
 int rf_set_tuning(const char* key, int value);
+/* Diagnostic hook: byte offset of a named array ("pmax", "cand", "thr") inside a search
+ * workspace, (size_t)-1 if unknown.  Used by tools/bench_wide.py to read clock stamps. */
+size_t rf_debug_workspace_offset(const char* field);
 /* Test hook: raw MFMA scan scores fp32 [B, n] for the first n rows. */
 int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,
                     float* out_dev, void* stream);

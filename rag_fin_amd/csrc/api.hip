@@ -3,6 +3,7 @@
 // {"metric_type": "COSINE"}, top_k, ...) -- vector_rag_mcp/main.py:51-57.
 #include "rf_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -36,6 +37,17 @@ static size_t carve(unsigned char* base, rf_workspace* ws) {
     ws->ex_row = exr;
   }
   return off;
+}
+
+// Diagnostic hook: byte offset of a named workspace array ("pmax", "cand", "thr").
+extern "C" size_t rf_debug_workspace_offset(const char* field) {
+  unsigned char* base = (unsigned char*)(uintptr_t)4096;   // never dereferenced
+  rf_workspace ws;
+  carve(base, &ws);
+  if (field && !strcmp(field, "pmax")) return (size_t)((unsigned char*)ws.pmax - base);
+  if (field && !strcmp(field, "cand")) return (size_t)((unsigned char*)ws.cand - base);
+  if (field && !strcmp(field, "thr")) return (size_t)((unsigned char*)ws.thr - base);
+  return (size_t)-1;
 }
 
 extern "C" size_t rf_search_workspace_bytes(const rf_index_t* ix) {
@@ -147,7 +159,12 @@ extern "C" int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, 
   for (int q0 = 0; q0 < B;) {
     const int left = B - q0;
     // more than one 64-query sweep left and dim 384: one wide sweep of up to 256 queries
-    const bool wide = wide_ok && left > RF_QCHUNK;
+    // (small corpora -- every row a candidate -- stay on the 64-query kernel: its inline flushes
+    // take any hit density, the wide kernel's bounded staging would flag every query)
+    // and so do large k (the k-th of ~64 partition maxima is a weak threshold) and k-dense searches
+    // of mid-sized corpora (expected hits per wave and phase ~ 2^15 k / N against room for 96)
+    const bool wide = wide_ok && left > RF_QCHUNK && ix->size > RF_SMALL_ROWS && k <= 16 &&
+                      ix->size >= (int64_t)k * 1024;
     const int nb = wide ? (left < RF_QWIDE ? left : RF_QWIDE) : (left < RF_QCHUNK ? left : RF_QCHUNK);
     const int JB = nb <= 32 ? 1 : 2;
     const _Float16* qc = (const _Float16*)q_dev + (size_t)q0 * dim;

@@ -112,3 +112,47 @@ __device__ __forceinline__ void emit_slow(const f32x16 (&acc)[JB], const float (
     bits &= bits - 1u;
   }
 }
+
+// Slow path, second form (wide sweep): one ballot per accumulator register instead of a
+// per-lane bit mask and a 32-way select chain.  A hit is rare (~0.3 per wave and block at the
+// default sample size) and almost always a single (query, row) pair, so the cost that matters
+// is the scan for it: per register one compare whose SGPR-pair result IS the ballot, one scalar
+// test, and the append only behind a taken branch.  `jb_hit` (wave-uniform) says which of the
+// query blocks needs scanning at all.
+// The staging area holds CAP entries and is flushed by the CALLER at one place per phase (an
+// inlined flush per append, or even per query block, multiplies the code and made hipcc spill
+// in the MFMA loop).  An append that does not fit -- more hits within one phase than the room
+// left at its start: duplicate-heavy or otherwise adversarial data -- is not stored; instead its query's candidate counter is pushed past the
+// list capacity, which the merge reports as RF_FLAG_CAND_OVERFLOW, and the caller answers that
+// query through the exhaustive path.
+template <int JB, int CAP, class P>
+__device__ __forceinline__ void emit_scan(const f32x16 (&acc)[JB], const float (&th)[JB],
+                                          const unsigned long long (&jb_hit)[JB], uint32_t row0,
+                                          int lane, EmitState& es, const P& p) {
+  const int h = lane >> 5;
+  const uint32_t lim = p.n_rows - row0;  // rows of this block that exist (0 for a block past the end)
+#pragma unroll
+  for (int jb = 0; jb < JB; ++jb) {
+    if (jb_hit[jb] == 0ull) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool ok = (acc[jb][i] >= th[jb]) && (acc_row(i, h) < lim);
+      const unsigned long long mask = __ballot(ok);
+      if (mask != 0ull) {
+        const uint32_t n = (uint32_t)__popcll(mask);
+        const uint32_t q = es.q_base + (uint32_t)(jb * 32 + (lane & 31));
+        if (es.cnt + n <= (uint32_t)CAP) {
+          if (ok) {
+            const uint32_t slot = es.cnt + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            es.s_row[slot] = row0 + acc_row(i, h);
+            es.s_score[slot] = acc[jb][i];
+            es.s_q[slot] = q;
+          }
+          es.cnt += n;
+        } else if (ok) {
+          atomicAdd(&p.cand_cnt[q * RF_CAND_SHARDS + (blockIdx.x & (RF_CAND_SHARDS - 1))], p.cap + 1u);
+        }
+      }
+    }
+  }
+}

@@ -230,6 +230,31 @@ def test_wide_sweep_parity(gpu_device, n, b, k):
     check_against_oracle(ix, q, c, k, gpu_device)
 
 
+def test_wide_sweep_duplicate_heavy_corpus_overflows_and_stays_exact(gpu_device):
+    """Every row ties for every query of a wide sweep: the per-wave staging of the wide
+    kernel and the candidate lists overflow, every query is flagged, and the exhaustive
+    path returns rows 0..k-1 by the tie rule.  A second corpus has ONE hot duplicate
+    group (500 copies of the best match of query 0): that query is flagged (and at most a
+    couple of others whose top-10 cut the tie group happens to straddle)."""
+    import torch
+    row = osearch.synth_unit_rows(1, 384, 15)
+    c = np.repeat(row, 30_000, axis=0)
+    q = osearch.synth_unit_rows(130, 384, 16)
+    ix = make_index(c, gpu_device)
+    _, _, _, flags = ix.search_raw(torch.from_numpy(q).to(gpu_device), 10)
+    assert (flags.cpu().numpy() != 0).all()
+    check_against_oracle(ix, q, c, 10, gpu_device, raw=False)
+
+    c2 = osearch.synth_unit_rows(60_000, 384, 17)
+    q2 = osearch.synth_unit_rows(200, 384, 18)
+    c2[1000:1500] = q2[0]
+    ix2 = make_index(c2, gpu_device)
+    _, _, _, f2 = ix2.search_raw(torch.from_numpy(q2).to(gpu_device), 10)
+    f2 = f2.cpu().numpy()
+    assert f2[0] != 0 and int((f2 != 0).sum()) <= 3   # a 500-way tie may straddle another query's cut too
+    check_against_oracle(ix2, q2, c2, 10, gpu_device, raw=False)
+
+
 def test_wide_sweep_equals_narrow_sweeps(gpu_device, monkeypatch):
     """The same 200 queries answered by one wide sweep and by 64-query sweeps."""
     import torch

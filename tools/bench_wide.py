@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""A/B timing of the wide sweep (65..256 queries per corpus pass) in ONE process:
+variants selected through rf_set_tuning, whole rf_search steps timed with HIP events
+(interleaved rounds, medians).  Prints per-step time, QPS and the corpus rate."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--variants", default="2:1,1:1,0:1",
+                    help="wide_variant:wide_nt pairs (0 register-staged, 1 LDS-DMA 4 waves, 2 LDS-DMA 8 waves)")
+    ap.add_argument("--dbg", type=int, default=0, help="ablation bits of the 4-wave kernel (results are then wrong)")
+    ap.add_argument("--check", action="store_true", help="compare ids of every variant with variant 0")
+    args = ap.parse_args()
+    import torch
+    from rag_fin_amd import _lib
+    from rag_fin_amd.store import GpuIndex
+    dev = torch.device("cuda:0")
+    dim = 384
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    c = torch.randn((args.rows, dim), generator=gen, device=dev)
+    c = (c / c.norm(dim=1, keepdim=True)).half()
+    q = torch.randn((args.batch, dim), generator=gen, device=dev)
+    q = (q / q.norm(dim=1, keepdim=True)).half()
+    ix = GpuIndex(dim, args.rows, dev)
+    ix.add(c)
+    del c
+    lib = _lib.load_library()
+    _lib.check(lib.rf_set_tuning(b"wide_dbg", args.dbg))
+    variants = [tuple(int(x) for x in v.split(":")) for v in args.variants.split(",")]
+
+    def apply(v):
+        _lib.check(lib.rf_set_tuning(b"wide_variant", v[0]))
+        _lib.check(lib.rf_set_tuning(b"wide_nt", v[1]))
+
+    ref = None
+    for v in variants:
+        apply(v)
+        for _ in range(3):
+            s, i, e, f = ix.search_raw(q, 10, want_exact=True)
+        torch.cuda.synchronize()
+        assert args.dbg or int(f.abs().sum()) == 0, ("flags", v)
+        if args.check:
+            if ref is None:
+                ref = (i.clone(), e.clone())
+            else:
+                assert torch.equal(ref[0], i) and torch.equal(ref[1], e), ("variant differs", v)
+    res = {v: [] for v in variants}
+    for _ in range(args.rounds):
+        for v in variants:
+            apply(v)
+            t0 = torch.cuda.Event(enable_timing=True)
+            t1 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+            for _ in range(args.reps):
+                ix.search_raw(q, 10, want_exact=True)
+            t1.record()
+            torch.cuda.synchronize()
+            res[v].append(t0.elapsed_time(t1) / args.reps)
+    if args.dbg & 4:
+        # clock stamps of the last launch: [workgroup][wave] x {cycles, 100-MHz ticks, wait cycles, phases}
+        off = lib.rf_debug_workspace_offset(b"pmax")
+        nw = 8 if variants[-1][0] == 2 else 4
+        st = ix.workspace[off:off + 256 * nw * 4 * 4].view(torch.float32).view(256, nw, 4).cpu().numpy()
+        cyc, ticks, wait, ph = st[..., 0], st[..., 1], st[..., 2], st[..., 3]
+        ok = ticks > 0
+        ghz = np.median(cyc[ok] / ticks[ok]) * 0.1
+        print("stamps: in-kernel clock %.2f GHz; loop %.1f us; cycles/phase %.0f; wait+barrier share %.1f %% "
+              "(median over workgroups x waves; phases %d..%d)" %
+              (ghz, np.median(ticks[ok]) / 100.0, np.median(cyc[ok] / ph[ok]),
+               100.0 * np.median(wait[ok] / cyc[ok]), ph[ok].min(), ph[ok].max()))
+    out = {}
+    for v in variants:
+        ms = float(np.median(res[v]))
+        out["variant%d_nt%d" % v] = {"ms_per_step": round(ms, 5), "qps": round(args.batch / ms * 1e3, 1),
+                                     "corpus_GBps": round(args.rows * dim * 2 / ms / 1e6, 1)}
+        print("wide_variant=%d nt=%d: %.1f us/step  %.0f QPS  %.0f GB/s" %
+              (v[0], v[1], ms * 1e3, args.batch / ms * 1e3, args.rows * dim * 2 / ms / 1e6))
+    print(json.dumps({"rows": args.rows, "batch": args.batch, "results": out}))
+
+
+if __name__ == "__main__":
+    main()

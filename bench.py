@@ -47,6 +47,7 @@ def parse():
                     help="batches in flight (one HIP stream + workspace each); 1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-batch256", action="store_true", help="skip the configs[2] (batch 256) side measurement")
     return ap.parse_args()
 
 
@@ -83,6 +84,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # RAGFIN_FORCE_SHARDED=1 at N=1: run the N>1 code path (scan -> RCCL all-gather -> merge) with
+    # a one-rank communicator, to measure its per-step overhead on a single-GPU box
+    force_sharded = world == 1 and os.environ.get("RAGFIN_FORCE_SHARDED") == "1"
+    if force_sharded:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                device_id=dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RAGFIN_DIST_BACKEND=gloo + RAGFIN_SHARE_GPU=1: rehearsal of the N>1 code path
@@ -108,7 +116,9 @@ def main():
     q = torch.from_numpy(q16).to(dev)
     torch.cuda.synchronize()
 
-    searcher = ShardedSearcher(HipShardBackend(index), row_base=rank * rows) if world > 1 else None
+    searcher = ShardedSearcher(HipShardBackend(index), row_base=rank * rows) if (world > 1 or force_sharded) else None
+    if force_sharded:
+        searcher.force_collective = True
     # `streams` batches in flight: each has its own HIP stream, workspace and output
     # buffers; the corpus index is immutable and shared.  Step i runs on lane i % lanes.
     max_lanes = max(1, args.streams)
@@ -197,7 +207,8 @@ def main():
                        else f"{rows} x {dim}-d fp16 corpus per GPU, batch-{B}, top-{k}",
                        "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "batch": B,
                        "topk": k, "batches_in_flight": n_lanes,
-                       "sharding": "none" if world == 1 else f"rows/{world} + RCCL all-gather"},
+                       "sharding": ("none" if not force_sharded else "one-rank RCCL all-gather (overhead rehearsal)")
+                       if world == 1 else f"rows/{world} + RCCL all-gather"},
             "rows_per_s": round(rows * world * args.steps / elapsed, 1),
             "serial": {"batches_in_flight": 1, "value": round(B * args.steps / serial_s, 1),
                        "ms_per_step": round(serial_s * 1e3 / args.steps, 5),
@@ -210,6 +221,31 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+
+        # ---- BASELINE.json configs[2]: the same corpus at batch 256 (one wide sweep per step,
+        # scan_wide.hip).  AI = 256 flop/B: the matrix pipe, at the clock the chip holds under
+        # MFMA load, is the binding roof there; both fractions are reported.  Serial steps.
+        if world == 1 and dim == 384 and not args.no_batch256:
+            B2 = 256
+            q2 = torch.from_numpy(osearch.synth_unit_rows(B2, dim, 5679)).to(dev)
+            for _ in range(5):
+                r2 = index.search_raw(q2, k, want_exact=True)
+            torch.cuda.synchronize()
+            n2 = max(20, args.steps // 4)
+            t0 = time.perf_counter()
+            for _ in range(n2):
+                r2 = index.search_raw(q2, k, want_exact=True)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / n2
+            flops2 = 2.0 * B2 * rows * dim
+            result["batch256"] = {
+                "workload": "%s x %d-d fp16 corpus, batch-256 queries, top-%d (configs[2])" % (f"{rows:,}", dim, k),
+                "value": round(B2 / dt2, 1), "unit": "queries/s", "ms_per_step": round(dt2 * 1e3, 5),
+                "steps": n2, "flags_clean": int(r2[3].abs().sum().item()) == 0,
+                "whole_step_GBps": round(alg_bytes / dt2 / 1e9, 1),
+                "hbm_frac": round(alg_bytes / dt2 / 1e9 / HBM_PEAK_GBPS, 4),
+                "whole_step_TFLOPs": round(flops2 / dt2 / 1e12, 1),
+                "mfma_frac_of_2500_dense_f16": round(flops2 / dt2 / 1e12 / 2500.0, 4)}
 
         # ---- correctness beside the number: recall@10 / exact ids vs the CPU oracle
         if not args.no_check:
@@ -241,9 +277,17 @@ def main():
                 times.append(time.perf_counter() - t)
             med = float(np.median(times))
             try:
-                cores = len(os.sched_getaffinity(0))
+                avail = len(os.sched_getaffinity(0))
             except AttributeError:
-                cores = os.cpu_count()
+                avail = os.cpu_count()
+            cores = avail
+            try:   # the threads the BLAS pool actually runs (it may be capped below the core count)
+                from threadpoolctl import threadpool_info
+                pools = [p_["num_threads"] for p_ in threadpool_info() if p_.get("user_api") == "blas"]
+                if pools:
+                    cores = min(avail, max(pools))
+            except Exception:
+                pass
             result["cpu_baseline"] = {
                 "value": round(B / med, 1), "unit": "queries/s", "cores": cores, "kind": "port",
                 "sample": f"{len(times)} full batches of the same workload ({rows} x {dim}, batch {B}, "
@@ -252,6 +296,7 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+    if world > 1 or force_sharded:
         dist.destroy_process_group()
 
 

@@ -123,6 +123,12 @@ int rf_search_exhaustive_after(const rf_index_t* ix, const void* q_dev, int B, i
  * reference is single-process); see SURVEY.md 8e. */
 int rf_merge_shards(const double* exact_dev, const int64_t* ids_dev, int W, int B, int k,
                     float* scores_out_dev, int64_t* ids_out_dev, void* stream);
+/* Same merge on the all-gather's own layout: packed_dev int64 [W][2][B][k], plane 0 = the
+ * fp64 ranking scores (bit patterns), plane 1 = the global row ids -- what each rank gets
+ * when rf_search writes exact_dev / ids_dev into the two halves of ONE send buffer, so that
+ * no repacking kernel runs between the scan, the collective and the merge. */
+int rf_merge_shards_packed(const int64_t* packed_dev, int W, int B, int k,
+                           float* scores_out_dev, int64_t* ids_out_dev, void* stream);
 /* Tuning hook (experiments / A-B runs in one process): key in {"ring24",
  * "emit_wgs_per_cu", "sample_bpw"}.  No reference counterpart. */
 int rf_set_tuning(const char* key, int value);

@@ -66,6 +66,7 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rf_merge_shards": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p]),
+    "rf_merge_shards_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rf_set_tuning": (c_int, [c_char_p, c_int]),
     "rf_debug_workspace_offset": (c_size_t, [c_char_p]),
     "rf_debug_scores": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),

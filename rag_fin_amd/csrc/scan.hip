@@ -213,7 +213,7 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t st) {
 
 // ---- tuning knobs (rf_set_tuning / environment at first use) ---------------------------
 extern int rf_tuning_fused;  // api.hip
-extern int rf_tuning_wide_variant, rf_tuning_wide_nt, rf_tuning_wide_dbg;  // scan_wide.hip
+extern int rf_tuning_wide_variant, rf_tuning_wide_nt, rf_tuning_wide_dbg, rf_tuning_wide_sample_pairs;  // scan_wide.hip
 struct ScanTuning {
   int ring24;           // register-ring depth (fragments) of the dim-384 kernels: 6 | 8 | 12 | 24
   int emit_wgs_per_cu;  // emit grid = CUs x this (0 = default for the dim)
@@ -237,6 +237,7 @@ extern "C" int rf_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "fused") && (value == 0 || value == 1)) rf_tuning_fused = value;
   else if (!strcmp(key, "wide_variant") && value >= 0 && value <= 2) rf_tuning_wide_variant = value;
   else if (!strcmp(key, "wide_nt") && (value == 0 || value == 1)) rf_tuning_wide_nt = value;
+  else if (!strcmp(key, "wide_sample_pairs") && value >= 1 && value <= 8) rf_tuning_wide_sample_pairs = value;
   else if (!strcmp(key, "wide_dbg") && value >= 0 && value <= 63) rf_tuning_wide_dbg = value;
   else {
     rf_set_error("rf_set_tuning: unknown key or bad value (%s = %d)", key, value);

@@ -536,6 +536,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_scan_ldsdma(WideParams p) {
 int rf_tuning_wide_variant = -1;   // 0 = register-staged form, 1 = LDS-DMA 4 waves, 2 = LDS-DMA 8 waves
 int rf_tuning_wide_nt = -1;        // LDS-DMA cache policy: 0 default, 1 non-temporal (aux = 2)
 int rf_tuning_wide_dbg = 0;        // ablation bits (WideParams::dbg)
+int rf_tuning_wide_sample_pairs = 4;   // sample pass: block pairs (phases) per workgroup, at most
 static int wide_variant() {
   if (rf_tuning_wide_variant < 0) {
     const char* v = getenv("RF_WIDE_VARIANT");
@@ -588,7 +589,7 @@ static int wide4_sample(const rf_index* ix, const void* q, int B, const rf_works
   // ~1/16 of the corpus in block pairs, 64..RF_SAMPLE_WGS partitions of up to 4 pairs
   uint32_t n_work = npair / 16;
   if (n_work < 64u) n_work = 64u;
-  if (n_work > (uint32_t)RF_SAMPLE_WGS * 4) n_work = (uint32_t)RF_SAMPLE_WGS * 4;
+  if (n_work > (uint32_t)RF_SAMPLE_WGS * rf_tuning_wide_sample_pairs) n_work = (uint32_t)RF_SAMPLE_WGS * rf_tuning_wide_sample_pairs;
   if (n_work > npair) n_work = npair;
   const int grid = (int)(n_work < (uint32_t)RF_SAMPLE_WGS ? n_work : (uint32_t)RF_SAMPLE_WGS);
   WideParams p{};

@@ -34,6 +34,42 @@ class HipShardBackend:
                                                           workspace=workspace)
         return exact, ids, flags
 
+    # -- low-overhead lane path: the scan writes straight into the all-gather's send buffer
+    # and the merge reads the receive buffer in place (no cat / contiguous / empty per step)
+    def new_lane(self, B: int, k: int, world: int):
+        import torch
+        dev = self.device
+        return dict(
+            B=B, k=k, world=world,
+            packed=torch.empty((2, B, k), dtype=torch.int64, device=dev),          # {score bits, ids}
+            flat=torch.empty((world, 2, B, k), dtype=torch.int64, device=dev),     # gathered
+            local_scores=torch.empty((B, k), dtype=torch.float32, device=dev),
+            flags=torch.empty((B,), dtype=torch.int32, device=dev),
+            scores=torch.empty((B, k), dtype=torch.float32, device=dev),
+            ids=torch.empty((B, k), dtype=torch.int64, device=dev))
+
+    def local_topk_into(self, q16, k: int, row_base: int, lane, workspace=None):
+        packed = lane["packed"]
+        self.index.search_raw(q16, k, id_base=row_base, want_exact=True, workspace=workspace,
+                              out=(lane["local_scores"], packed[1], packed[0].view(self._f64()), lane["flags"]))
+
+    def merge_packed(self, flat, lane):
+        with self._device_ctx():
+            _lib.check(self.lib.rf_merge_shards_packed(
+                c_void_p(flat.data_ptr()), lane["world"], lane["B"], lane["k"],
+                c_void_p(lane["scores"].data_ptr()), c_void_p(lane["ids"].data_ptr()),
+                _lib.current_stream_ptr()))
+        return lane["scores"], lane["ids"]
+
+    @staticmethod
+    def _f64():
+        import torch
+        return torch.float64
+
+    def _device_ctx(self):
+        import torch
+        return torch.cuda.device(self.device)
+
     def merge(self, exact_all, ids_all, k: int):
         import torch
         W, B, _ = exact_all.shape
@@ -57,6 +93,34 @@ class ShardedSearcher:
         self.dist = dist
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._lanes = {}
+        # world 1 normally skips the collective; set to run it anyway (overhead measurements)
+        self.force_collective = False
+
+    def _search_lane(self, q16, k: int, workspace):
+        """Product path (HipShardBackend): per-(workspace, B, k) preallocated buffers; the
+        returned tensors are those buffers -- consume them before the same lane searches
+        again.  Three enqueues per step: rf_search, all_gather_into_tensor, merge."""
+        B = q16.shape[0]
+        key = (workspace.data_ptr() if workspace is not None else 0, B, k)
+        lane = self._lanes.get(key)
+        if lane is None:
+            lane = self._lanes[key] = self.backend.new_lane(B, k, self.world)
+        self.backend.local_topk_into(q16, k, self.row_base, lane, workspace)
+        if self.world == 1 and not self.force_collective:
+            flat = lane["packed"]
+        else:
+            flat = lane["flat"]
+            inp, outp = lane["packed"].view(2 * B, k), flat.view(self.world * 2 * B, k)
+            if self.dist.get_backend(self.group) == "gloo":
+                # rehearsal path (gloo has no device all-gather): stage through the host
+                host = outp.cpu()
+                self.dist.all_gather_into_tensor(host, inp.cpu(), group=self.group)
+                outp.copy_(host)
+            else:
+                self.dist.all_gather_into_tensor(outp, inp, group=self.group)
+        scores, gids = self.backend.merge_packed(flat, lane)
+        return scores, gids, lane["flags"]
 
     @staticmethod
     def shard_bounds(n_total: int, world: int, rank: int):
@@ -74,6 +138,8 @@ class ShardedSearcher:
         `workspace` each (GpuIndex.new_workspace()); every rank must issue its searches
         in the same order, because the all-gathers share one communicator."""
         import torch
+        if hasattr(self.backend, "local_topk_into"):
+            return self._search_lane(q16, k, workspace)
         if workspace is None:
             exact, ids, flags = self.backend.local_topk(q16, k, self.row_base)
         else:

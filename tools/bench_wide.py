@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--variants", default="2:1,1:1,0:1",
                     help="wide_variant:wide_nt pairs (0 register-staged, 1 LDS-DMA 4 waves, 2 LDS-DMA 8 waves)")
+    ap.add_argument("--sample-pairs", type=int, default=4)
     ap.add_argument("--dbg", type=int, default=0, help="ablation bits of the 4-wave kernel (results are then wrong)")
     ap.add_argument("--check", action="store_true", help="compare ids of every variant with variant 0")
     args = ap.parse_args()
@@ -38,6 +39,7 @@ def main():
     del c
     lib = _lib.load_library()
     _lib.check(lib.rf_set_tuning(b"wide_dbg", args.dbg))
+    _lib.check(lib.rf_set_tuning(b"wide_sample_pairs", args.sample_pairs))
     variants = [tuple(int(x) for x in v.split(":")) for v in args.variants.split(",")]
 
     def apply(v):

@@ -90,18 +90,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_scan(ScanParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dim = KS * 16;
 
-  // stage the queries in B-fragment order: lane (j = l & 31, h = l >> 5) of
-  // fragment (jb, kk) holds q[32 jb + j][16 kk + 8 h .. +8)
-  for (int idx = tid; idx < JB * KS * 64; idx += WAVES * 64) {
-    const int l = idx & 63;
-    const int kk = (idx >> 6) % KS;
-    const int jb = idx / (64 * KS);
-    const int qi = jb * 32 + (l & 31);
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (qi < p.B) v = *(const u32x4*)(p.q + (size_t)qi * dim + kk * 16 + (l >> 5) * 8);
-    smemQ[idx] = v;
-  }
-
   float th[JB];
   float pm[JB];
 #pragma unroll
@@ -121,7 +109,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_scan(ScanParams p) {
     es.s_score = nullptr;
     es.s_q = nullptr;
   }
-  __syncthreads();
 
   // work items w = gw, gw + W, ...  (one item = one 32-row block)
   const uint32_t W = gridDim.x * WAVES;
@@ -133,6 +120,23 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_scan(ScanParams p) {
     const uint4* src = p.corpus + (size_t)gw * p.bstride * (KS * 64) + lane;
 #pragma unroll
     for (int s = 0; s < R; ++s) ring[s] = ld_frag(src + s * 64);
+  }
+  // (the corpus stream starts BEFORE the queries are staged: the first HBM round trip runs
+  // under the staging loop and its barrier instead of after them)
+  // stage the queries in B-fragment order: lane (j = l & 31, h = l >> 5) of
+  // fragment (jb, kk) holds q[32 jb + j][16 kk + 8 h .. +8)
+  for (int idx = tid; idx < JB * KS * 64; idx += WAVES * 64) {
+    const int l = idx & 63;
+    const int kk = (idx >> 6) % KS;
+    const int jb = idx / (64 * KS);
+    const int qi = jb * 32 + (l & 31);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (qi < p.B) v = *(const u32x4*)(p.q + (size_t)qi * dim + kk * 16 + (l >> 5) * 8);
+    smemQ[idx] = v;
+  }
+
+  __syncthreads();
+  if (cnt > 0) {
 
     uint32_t w = gw;
     for (uint32_t i = 0; i + 1 < cnt; ++i, w += W) {
@@ -163,6 +167,110 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_scan(ScanParams p) {
       p.pmax[(size_t)tid * p.P + blockIdx.x] = m;
     }
   }
+}
+
+// ---- emit sweep with the queries in registers (dim 384, 33..64 queries; EXPERIMENT) --------
+// k_scan re-reads its query fragments from LDS at every k-step (two ds_read_b128 per MFMA
+// pair), and the 64-query sweep is ~4 % slower than the 32-query one (120.6 vs 115.6 us at
+// 1M x 384, where a bare streaming read of the same bytes takes 111.6 us).  This form tests
+// whether that LDS traffic is the cost: a wave keeps all 64 queries as 48 B-operand fragments
+// in the accumulator half of its register file (one wave per SIMD, the whole 512-register
+// file), streams its corpus blocks through a full-block register ring and touches LDS only to
+// stage the rare hits -- no barrier, no LDS in the loop.  Measured: 122.0 us against 120.2 us
+// for k_scan in the same process, i.e. the LDS reads are NOT what the second MFMA per
+// fragment costs (the sweep slows with the matrix work itself: the chip trades clock and
+// fabric rate for MFMA power).  Kept behind rf_set_tuning("qreg", 1) / RF_QREG=1, parity-tested.
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k_scan_qreg(ScanParams p) {
+  constexpr int KS = 24, R = 24, JB = 2, WAVES = 4;
+  __shared__ __attribute__((aligned(16))) uint32_t stage_lds[3 * WAVES * SCAP];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+
+  const uint32_t W = gridDim.x * WAVES;
+  const uint32_t gw = blockIdx.x * WAVES + wave;
+  const uint32_t cnt = (p.n_work > gw) ? (p.n_work - gw + W - 1) / W : 0u;
+  if (cnt == 0) return;   // no barrier anywhere in this kernel
+
+  u32x4 ring[R];
+  {
+    const uint4* src = p.corpus + (size_t)gw * p.bstride * (KS * 64) + lane;
+#pragma unroll
+    for (int s = 0; s < R; ++s) ring[s] = ld_frag(src + s * 64);
+  }
+  u32x4 qf[JB][KS];
+  float th[JB], pm[JB];
+#pragma unroll
+  for (int jb = 0; jb < JB; ++jb) {
+    const int qi = jb * 32 + c;
+    const int qc = qi < p.B ? qi : p.B - 1;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+      qf[jb][kk] = *(const u32x4*)(p.q + (size_t)qc * (KS * 16) + kk * 16 + h * 8);
+    pm[jb] = -INFINITY;
+    th[jb] = (MODE == MODE_EMIT) ? p.thr[qc] : 0.f;
+    if (qi >= p.B) th[jb] = INFINITY;
+  }
+#pragma unroll
+  for (int jb = 0; jb < JB; ++jb) {
+    const int qi = jb * 32 + c;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      u32x4 v = qf[jb][kk];
+      if (qi >= p.B) v = u32x4{0u, 0u, 0u, 0u};
+      asm volatile("" : "+a"(v));   // resident in the accumulator half (MFMA reads B from either)
+      qf[jb][kk] = v;
+    }
+  }
+  EmitState es;
+  es.cnt = 0;
+  es.q_base = 0;
+  es.s_row = stage_lds + wave * SCAP;
+  es.s_score = (float*)(stage_lds + WAVES * SCAP) + wave * SCAP;
+  es.s_q = stage_lds + 2 * WAVES * SCAP + wave * SCAP;
+
+  uint32_t w = gw;
+  for (uint32_t i = 0; i < cnt; ++i, w += W) {
+    const uint32_t b = w * p.bstride;
+    // the last block re-arms from itself (loads discarded): every load unconditional
+    const uint32_t bn = (i + 1 < cnt) ? b + W * p.bstride : b;
+    const uint4* nxt = p.corpus + (size_t)bn * (KS * 64) + lane;
+    f32x16 acc[JB];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const half8 a = __builtin_bit_cast(half8, ring[kk]);
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) {
+        if (kk == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, qf[jb][kk]), z, 0, 0, 0);
+        } else {
+          acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, qf[jb][kk]), acc[jb], 0, 0, 0);
+        }
+      }
+      ring[kk] = ld_frag(nxt + kk * 64);
+    }
+    const uint32_t row0 = b * 32u;
+    if (MODE == MODE_SAMPLE) {
+      if (row0 + 32u > p.n_rows) {
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (row0 + acc_row(r, h) >= p.n_rows) acc[jb][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) pm[jb] = fmaxf(pm[jb], max16(acc[jb]));
+    } else {
+      bool hit = false;
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) hit |= (max16(acc[jb]) >= th[jb]);
+      if (__ballot(hit) != 0ull) emit_slow<JB>(acc, th, row0, lane, es, p);
+    }
+  }
+  if (MODE == MODE_EMIT && es.cnt > 0) emit_flush(es, p, lane);
 }
 
 // ---- raw score dump (test hook) ---------------------------------------------
@@ -218,6 +326,7 @@ struct ScanTuning {
   int ring24;           // register-ring depth (fragments) of the dim-384 kernels: 6 | 8 | 12 | 24
   int emit_wgs_per_cu;  // emit grid = CUs x this (0 = default for the dim)
   int sample_bpw;       // sample blocks per wave
+  int qreg;             // dim 384, 33..64 queries: emit sweep with the queries in registers (k_scan_qreg)
 };
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -225,7 +334,7 @@ static int env_int(const char* name, int dflt) {
 }
 static ScanTuning& tuning() {
   static ScanTuning t = {env_int("RF_RING24", 8), env_int("RF_EMIT_WGS_PER_CU", 0),
-                         env_int("RF_SAMPLE_BPW", 2)};
+                         env_int("RF_SAMPLE_BPW", 2), env_int("RF_QREG", 0)};
   return t;
 }
 extern "C" int rf_set_tuning(const char* key, int value) {
@@ -234,6 +343,7 @@ extern "C" int rf_set_tuning(const char* key, int value) {
   if (!strcmp(key, "ring24") && (value == 6 || value == 8 || value == 12 || value == 24)) t.ring24 = value;
   else if (!strcmp(key, "emit_wgs_per_cu") && value >= 0 && value <= 4) t.emit_wgs_per_cu = value;
   else if (!strcmp(key, "sample_bpw") && value >= 1 && value <= 8) t.sample_bpw = value;
+  else if (!strcmp(key, "qreg") && (value == 0 || value == 1)) t.qreg = value;
   else if (!strcmp(key, "fused") && (value == 0 || value == 1)) rf_tuning_fused = value;
   else if (!strcmp(key, "wide_variant") && value >= 0 && value <= 2) rf_tuning_wide_variant = value;
   else if (!strcmp(key, "wide_nt") && (value == 0 || value == 1)) rf_tuning_wide_nt = value;
@@ -357,6 +467,15 @@ int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_wo
   p.cand_cnt = ws.cand_cnt;
   p.cand = ws.cand;
   p.cap = RF_SHARD_CAP;
+  if (KS == 24 && JB == 2 && tuning().qreg) {
+    // queries in registers: one 4-wave workgroup per CU (one wave per SIMD)
+    int g = ix->num_cus;
+    const uint32_t need4 = (nblk + 3) / 4;
+    if ((uint32_t)g > need4) g = (int)need4;
+    hipLaunchKernelGGL(k_scan_qreg<MODE_EMIT>, dim3(g), dim3(256), 0, st, p);
+    RF_HIP(hipGetLastError());
+    return RF_OK;
+  }
   return dispatch_scan<MODE_EMIT>(KS, JB, p, grid, grid, st);
 }
 

@@ -298,7 +298,7 @@ def test_tuning_variants_stay_exact(gpu_device):
     q = torch.from_numpy(q16).to(gpu_device)
     try:
         for key, values in (("ring24", (6, 12, 24, 8)), ("emit_wgs_per_cu", (1, 3, 0)),
-                            ("sample_bpw", (1, 4, 2)), ("fused", (1, 0))):
+                            ("sample_bpw", (1, 4, 2)), ("fused", (1, 0)), ("qreg", (1, 0))):
             for v in values:
                 _lib.check(lib.rf_set_tuning(key.encode(), v))
                 s, i, e, f = ix.search_raw(q, 10, want_exact=True)
@@ -308,5 +308,5 @@ def test_tuning_variants_stay_exact(gpu_device):
                 assert np.array_equal(e.cpu().numpy(), os_), (key, v)
         assert lib.rf_set_tuning(b"ring24", 7) != 0 and lib.rf_set_tuning(b"nope", 1) != 0
     finally:
-        for key, v in (("ring24", 8), ("emit_wgs_per_cu", 0), ("sample_bpw", 2), ("fused", 0)):
+        for key, v in (("ring24", 8), ("emit_wgs_per_cu", 0), ("sample_bpw", 2), ("fused", 0), ("qreg", 0)):
             lib.rf_set_tuning(key.encode(), v)

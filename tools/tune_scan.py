@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--wgs", default="2,3")
     ap.add_argument("--bpw", default="1,2")
     ap.add_argument("--fused", default="0")
+    ap.add_argument("--qreg", default="0", help="dim-384 emit sweep with the queries in registers: 0,1")
     args = ap.parse_args()
     import torch
     from rag_fin_amd import _lib
@@ -38,13 +39,14 @@ def main():
     ix.add(c)
     lib = _lib.load_library()
     configs = list(itertools.product([int(x) for x in args.rings.split(",")], [int(x) for x in args.wgs.split(",")],
-                                     [int(x) for x in args.bpw.split(",")], [int(x) for x in args.fused.split(",")]))
+                                     [int(x) for x in args.bpw.split(",")], [int(x) for x in args.fused.split(",")],
+                                     [int(x) for x in args.qreg.split(",")]))
     res = {cfg: [] for cfg in configs}
     flags_bad = {cfg: 0 for cfg in configs}
 
     def apply(cfg):
-        ring, wgs, bpw, fused = cfg
-        for k, v in (("ring24", ring), ("emit_wgs_per_cu", wgs), ("sample_bpw", bpw), ("fused", fused)):
+        ring, wgs, bpw, fused, qreg = cfg
+        for k, v in (("ring24", ring), ("emit_wgs_per_cu", wgs), ("sample_bpw", bpw), ("fused", fused), ("qreg", qreg)):
             _lib.check(lib.rf_set_tuning(k.encode(), v))
 
     for cfg in configs:  # warm every variant (first launch loads code, sets LDS attributes)
@@ -58,14 +60,14 @@ def main():
             res[cfg].append({k: float(np.median([s[k] for s in stages])) for k in stages[0]})
             _, _, _, f = ix.search_raw(q, 10)
             flags_bad[cfg] += int(f.abs().sum().item())
-    print("ring wgs bpw fused | sample thr emit merge | total (us, median of round medians)")
+    print("ring wgs bpw fused qreg | sample thr emit merge | total (us, median of round medians)")
     rows = []
     for cfg in configs:
         med = {k: float(np.median([r[k] for r in res[cfg]])) * 1e3 for k in res[cfg][0]}
         tot = sum(med.values())
         rows.append((tot, cfg, med))
     for tot, cfg, med in sorted(rows):
-        print("%4d %3d %3d %5d | %6.1f %5.1f %6.1f %5.1f | %6.1f  flags=%d" %
+        print("%4d %3d %3d %5d %4d | %6.1f %5.1f %6.1f %5.1f | %6.1f  flags=%d" %
               (*cfg, med["sample"], med["threshold"], med["emit"], med["merge"], tot, flags_bad[cfg]))
     print(json.dumps({"best": {"ring24": rows and sorted(rows)[0][1][0]}}))
 

@@ -51,14 +51,14 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(rows, dim):
+def pmc_traffic(rows, dim, batch):
     """HBM bytes per emit-scan launch from the committed PMC passes, if they were
     taken on this workload (profiles/*_pmc.json; see DESIGN.md 'Measurement')."""
     try:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
             rec = json.load(open(path))
-            if rec.get("rows") == rows and rec.get("dim") == dim:
+            if rec.get("rows") == rows and rec.get("dim") == dim and rec.get("batch") == batch:
                 return rec.get("hbm_bytes_per_launch")
     except Exception:
         pass
@@ -194,7 +194,7 @@ def main():
         stage_avg = {n: float(np.mean([s[n] for s in stages])) for n in stages[0]}
         alg_bytes = rows * dim * 2  # corpus read once per batch
         achieved = alg_bytes / (emit_ms * 1e-3) / 1e9
-        traffic = pmc_traffic(rows, dim)
+        traffic = pmc_traffic(rows, dim, B)
         result = {
             "metric": "queries/sec, brute-force cosine/IP top-%d over a %s x %d-d fp16 corpus, "
                       "batch=%d (recall@10 vs CPU oracle reported alongside)" % (k, f"{rows:,}", dim, B),

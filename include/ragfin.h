@@ -135,6 +135,9 @@ int rf_set_tuning(const char* key, int value);
 /* Diagnostic hook: byte offset of a named array ("pmax", "cand", "thr") inside a search
  * workspace, (size_t)-1 if unknown.  Used by tools/bench_wide.py to read clock stamps. */
 size_t rf_debug_workspace_offset(const char* field);
+/* Diagnostic hook: a device buffer (>= 64 KiB, or NULL to switch off) that instrumented
+ * kernels fill with clock stamps (encoder k_linear_dma: 8 floats per wave). */
+int rf_debug_set_buffer(void* dev_ptr);
 /* Test hook: raw MFMA scan scores fp32 [B, n] for the first n rows. */
 int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,
                     float* out_dev, void* stream);

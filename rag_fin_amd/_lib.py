@@ -69,6 +69,7 @@ SIGNATURES = {
     "rf_merge_shards_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rf_set_tuning": (c_int, [c_char_p, c_int]),
     "rf_debug_workspace_offset": (c_size_t, [c_char_p]),
+    "rf_debug_set_buffer": (c_int, [c_void_p]),
     "rf_debug_scores": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "rf_encoder_storage_bytes": (c_size_t, [POINTER(EncoderConfig)]),
     "rf_encoder_create": (c_int, [POINTER(c_void_p), POINTER(EncoderConfig),

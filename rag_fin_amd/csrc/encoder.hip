@@ -22,6 +22,7 @@
 //                   kept for longer sequences
 //   k_pool_norm     mean over the sequence, L2-normalise                      (K7)
 #include "rf_internal.h"
+#include "lds_ring.h"
 #include <new>
 #include <stdlib.h>
 
@@ -145,7 +146,7 @@ static size_t enc_carve(unsigned char* base, int B, int T, int I, EncWs* ws) {
     off = (off + bytes + 255) / 256 * 256;
     return p;
   };
-  const size_t Mpad = ((size_t)B * T + 63) / 64 * 64;
+  const size_t Mpad = ((size_t)B * T + 127) / 128 * 128;   // k_linear_dma reads whole 128-token tiles
   int32_t* tok = (int32_t*)take(((size_t)B + 1) * 4);
   _Float16* x = (_Float16*)take(Mpad * HID * 2);
   _Float16* y = (_Float16*)take(Mpad * HID * 2);
@@ -265,6 +266,35 @@ __device__ __forceinline__ float erf_fast(float x) {
 __device__ __forceinline__ float gelu_erf(float y) {
   return 0.5f * y * (1.f + erf_fast(y * 0.70710678118654752f));
 }
+// The same arithmetic on two elements per lane with v_pk_fma_f32 / v_pk_mul_f32 (full rate on
+// two floats): 12 packed ops + 2 rcp + 2 exp per PAIR instead of ~14 + 2 per element.  The
+// GELU epilogue of the 1536-wide FFN GEMM is VALU-bound (50 M evaluations per layer call).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 y) {
+  const f32x2 x = y * 0.70710678118654752f;
+  f32x2 ax;
+  ax[0] = fabsf(x[0]);
+  ax[1] = fabsf(x[1]);
+  const f32x2 d = __builtin_elementwise_fma(ax, f32x2{0.3275911f, 0.3275911f}, f32x2{1.f, 1.f});
+  f32x2 t;
+  t[0] = __builtin_amdgcn_rcpf(d[0]);
+  t[1] = __builtin_amdgcn_rcpf(d[1]);
+  f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(t, p, f32x2{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(t, p, f32x2{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(t, p, f32x2{0.254829592f, 0.254829592f});
+  p = p * t;
+  const f32x2 e = ax * ax * -1.4426950408889634f;   // exp(-ax^2) = exp2(-ax^2 log2 e)
+  f32x2 ex;
+  ex[0] = __builtin_amdgcn_exp2f(e[0]);
+  ex[1] = __builtin_amdgcn_exp2f(e[1]);
+  const f32x2 r = __builtin_elementwise_fma(-p, ex, f32x2{1.f, 1.f});   // erf(|x|)
+  f32x2 sg;
+  sg[0] = copysignf(r[0], x[0]);
+  sg[1] = copysignf(r[1], x[1]);
+  const f32x2 hy = y * 0.5f;
+  return __builtin_elementwise_fma(hy, sg, hy);
+}
 
 // Y[tokens, N] = X[tokens, K] W^T + b with W in the fragment tiling.  Workgroup =
 // 32*NTB tokens x 384 features (grid.y picks the 384-feature group); wave w owns
@@ -359,11 +389,19 @@ __global__ void __launch_bounds__(256) k_linear(
       for (int g = 0; g < 4; ++g) {
         const int f = fgroup + 32 * fb + 8 * g + 4 * h;
         const half4 bv = *(const half4*)(bias + f);
+        if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float y = acc[tb][fb][4 * g + j] + (float)bv[j];
-          if (EPI == EPI_BIAS_GELU) y = gelu_erf(y);
-          v[fb][4 * g + j] = y;
+          for (int j = 0; j < 4; j += 2) {
+            f32x2 y;
+            y[0] = acc[tb][fb][4 * g + j] + (float)bv[j];
+            y[1] = acc[tb][fb][4 * g + j + 1] + (float)bv[j + 1];
+            y = gelu_erf2(y);
+            v[fb][4 * g + j] = y[0];
+            v[fb][4 * g + j + 1] = y[1];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[fb][4 * g + j] = acc[tb][fb][4 * g + j] + (float)bv[j];
         }
         if (EPI == EPI_BIAS_RES_LN) {
           const half4 rv = *(const half4*)(res + toff(token, f, HID / 16));
@@ -416,6 +454,194 @@ __global__ void __launch_bounds__(256) k_linear(
           *(half4*)(out + toff(token, f, ldo / 16)) = o;
         }
     }
+  }
+}
+
+// ---- K = 384 GEMMs with plain epilogues (QKV, FFN1): weights through an LDS-DMA ring -------
+// k_linear above loads BOTH operands of every k-step straight from L1/L2 into registers, per
+// wave: 5 KiB of fragment loads per 6 MFMAs, and the texture-addresser path, not the matrix
+// pipe, sets its pace (~1.7 x the MFMA time).  This form is the batch-256 corpus sweep
+// (scan_wide.hip) with the roles renamed:
+//   * a wave keeps ITS 32 tokens' activations resident as 24 B-operand fragments (96 registers,
+//     pinned to the accumulator half of the register file) for the whole kernel;
+//   * the weight matrix streams through a 3-slot LDS ring by LDS-DMA, two 32-feature blocks
+//     (48 KiB) per phase, loads two phases ahead behind a counted vmcnt and a raw s_barrier;
+//     all eight waves of the workgroup read it from LDS (inline-asm ds_read_b128, lds_ring.h),
+//     so a weight byte crosses the load path once per 128 tokens instead of once per wave;
+//   * workgroup = 128 tokens x ALL N features: waves w and w + 4 share a token block and a
+//     SIMD and take the even / odd feature block of each phase, so one's epilogue (bias, GELU,
+//     fp16 stores) runs under the other's MFMAs;
+//   * the bias vector sits in LDS and is read with inline-asm ds_read_b64 (an ordinary global
+//     load in the loop would make hipcc wait vmcnt(0) and drain the ring).
+#define LD_TOK 128
+#define LD_WAVES 8
+#define LD_SLOTS 3
+#define LD_FRAGS 48                       // fragments per phase: 2 feature blocks x 24 k-steps
+#define LD_PW (LD_FRAGS / LD_WAVES)       // LDS-DMA pieces per wave and phase (6)
+template <int EPI>
+__global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
+    const _Float16* __restrict__ X, const uint4* __restrict__ Wt, const _Float16* __restrict__ bias,
+    _Float16* __restrict__ out, int N, const int32_t* __restrict__ m_ptr, float* __restrict__ dbg, int dbg_flags) {
+  constexpr int KS = HID / 16;   // 24
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // diagnostic run only (dbg != nullptr, tools/bench_encode.py --stamps): clock stamps per wave
+  const uint64_t ts_entry = dbg ? __builtin_amdgcn_s_memtime() : 0;
+  const uint64_t tr_entry = dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+  uint64_t ts_loop = 0, t_wait = 0;
+  rf_u32x4* slots = (rf_u32x4*)smem_raw;                      // [3][48 * 64]
+  rf_u32x4* const dump = slots + LD_SLOTS * LD_FRAGS * 64;    // 1 KiB
+  _Float16* bias_l = (_Float16*)(dump + 64);                  // [N]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int t0 = blockIdx.x * LD_TOK;
+  const int M = *m_ptr;
+  if (t0 >= M) return;   // whole workgroup
+  const int tb = wave & 3, par = wave >> 2;
+  const uint32_t n_ph = (uint32_t)N / 64u;
+  const uint32_t nblk = (uint32_t)N / 32u;
+
+  struct Pieces {
+    const uint4* src;
+    rf_u32x4* dst;
+    int dstep, sstep;
+  };
+  auto pieces_of = [&](uint32_t ph) {
+    const bool live = ph < n_ph;
+    uint32_t b = 2u * ph + (uint32_t)(wave >> 2);
+    b = live ? b : nblk - 1u;
+    Pieces pc;
+    pc.src = Wt + ((size_t)b * KS + (wave & 3) * LD_PW) * 64 + lane;
+    pc.dst = live ? slots + ((ph % LD_SLOTS) * LD_FRAGS + wave * LD_PW) * 64 : dump;
+    pc.dstep = live ? 64 : 0;
+    pc.sstep = 64;
+    if (dbg_flags & 1) {   // ablation (wrong results): every piece re-reads one cached KiB
+      pc.src = Wt + lane;
+      pc.sstep = 0;
+    }
+    return pc;
+  };
+  auto issue_piece = [&](const Pieces& pc, int j) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pc.src + j * pc.sstep),
+                                     (__attribute__((address_space(3))) void*)(pc.dst + j * pc.dstep), 16, 0, 0);
+  };
+  {
+    const Pieces p0 = pieces_of(0), p1 = pieces_of(1);
+#pragma unroll
+    for (int j = 0; j < LD_PW; ++j) issue_piece(p0, j);
+#pragma unroll
+    for (int j = 0; j < LD_PW; ++j) issue_piece(p1, j);
+  }
+  // this wave's 32 tokens as B-operand fragments (fragment (token block, kk) = 1 KiB contiguous)
+  rf_u32x4 xf[KS];
+  {
+    const _Float16* xfrag = X + (((size_t)(t0 >> 5) + tb) * KS * 64 + lane) * 8;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) xf[kk] = *(const rf_u32x4*)(xfrag + (size_t)kk * 512);
+  }
+  for (int i = tid; i < N / 8; i += LD_WAVES * 64) *(uint4*)(bias_l + i * 8) = *(const uint4*)(bias + i * 8);
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    rf_u32x4 v = xf[kk];
+    asm volatile("" : "+a"(v));
+    xf[kk] = v;
+  }
+  __syncthreads();   // bias in LDS (this barrier also drains the first DMA pieces: needed at once anyway)
+
+  // lane's slot in the tiled output: token block (t0/32 + tb), feature 4 h, lane c (see toff())
+  _Float16* const out_lane = out + (((size_t)(t0 >> 5) + tb) * (size_t)(N / 16) * 64 + c) * 8 + 4 * h;
+  const uint32_t bias_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)bias_l + (uint32_t)h * 8u;
+  f32x16 acc;
+  // matrix part of a phase: this wave's feature block (par) of the slot x its 32 tokens
+  auto mfma_part = [&](uint32_t ph, const Pieces& nxt) {
+    const rf_u32x4* slot = slots + ((ph % LD_SLOTS) * LD_FRAGS + par * KS) * 64 + lane;
+    const uint32_t sa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)slot;
+    rf_u32x4 fa[2][WL_GRP];
+    constexpr int NG = KS / WL_GRP;   // 6
+    lds_read_group<0>(fa[0], sa);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) {
+        lds_read_group_dyn(fa[(g + 1) & 1], sa, (g + 1) * WL_GRP);
+        lds_wait_group<WL_GRP>(fa[g & 1]);
+      } else {
+        lds_wait_group<0>(fa[g & 1]);
+      }
+      if (g < LD_PW && !(dbg_flags & 2)) issue_piece(nxt, g);   // one LDS-DMA piece per group of 4 MFMAs
+#pragma unroll
+      for (int j = 0; j < WL_GRP; ++j) {
+        const int kk = g * WL_GRP + j;
+        const half8 a = __builtin_bit_cast(half8, fa[g & 1][j]);
+        if (kk == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), z, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), acc, 0, 0, 0);
+        }
+      }
+    }
+  };
+  // epilogue of one finished block: acc[4 g + j] = Y[token][32 blk + 8 g + 4 h + j]
+  auto epilogue = [&](uint32_t blk) {
+    uint2 bq[4];
+    const uint32_t ba = bias_a + blk * 64u;   // bias of the lane's 16 features
+    asm volatile("ds_read_b64 %0, %1 offset:0" : "=v"(bq[0]) : "v"(ba));
+    asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(bq[1]) : "v"(ba));
+    asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(bq[2]) : "v"(ba));
+    asm volatile("ds_read_b64 %0, %1 offset:48" : "=v"(bq[3]) : "v"(ba));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const half4 bv = __builtin_bit_cast(half4, bq[g]);
+      half4 o;
+      if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          f32x2 y;
+          y[0] = acc[4 * g + j] + (float)bv[j];
+          y[1] = acc[4 * g + j + 1] + (float)bv[j + 1];
+          y = gelu_erf2(y);
+          o[j] = (_Float16)y[0];
+          o[j + 1] = (_Float16)y[1];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (_Float16)(acc[4 * g + j] + (float)bv[j]);
+      }
+      // unconditional: rows >= M of the last tile exist (the workspace is padded to whole tiles) and
+      // nobody reads them -- and a fixed 4 stores per phase keeps the vmcnt arithmetic exact.
+      // toff(token, 32 blk + 8 g + 4 h) = per-lane base + a wave-uniform offset:
+      *(half4*)(out_lane + ((size_t)blk * 2 + (g >> 1)) * 512 + (g & 1) * 256) = o;
+    }
+  };
+  if (dbg) ts_loop = __builtin_amdgcn_s_memtime();
+  for (uint32_t ph = 0; ph < n_ph; ++ph) {
+    uint64_t ts0 = 0;
+    if (dbg) ts0 = __builtin_amdgcn_s_memtime();
+    // the previous phase issued, after the barrier that follows my pieces of phase ph, exactly 6
+    // pieces (phase ph+1) and 4 stores: those 10 may stay in flight, everything older has landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + 4) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (dbg) t_wait += __builtin_amdgcn_s_memtime() - ts0;
+    const Pieces nxt = pieces_of(ph + 2);
+    // Tried and dropped: running the two waves of a SIMD (w and w + 4) through the phase in
+    // OPPOSITE orders (one's MFMAs over the other's epilogue and DMA issues, pieces issued in a
+    // burst): 5 300 cycles per phase instead of 4 300 -- a burst of six LDS-DMA issues costs more
+    // than six issues spread over the MFMA groups.
+    mfma_part(ph, nxt);
+    if (!(dbg_flags & 4)) epilogue(2u * ph + (uint32_t)par);
+  }
+  if (dbg_flags & 4) asm volatile("" : "+a"(acc));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump pieces must land before the LDS is handed on
+  if (dbg && lane == 0) {
+    float* o = dbg + ((size_t)blockIdx.x * LD_WAVES + wave) * 8;
+    const uint64_t te = __builtin_amdgcn_s_memtime();
+    o[0] = (float)(te - ts_entry);                                  // cycles, whole kernel
+    o[1] = (float)(__builtin_amdgcn_s_memrealtime() - tr_entry);    // 100-MHz ticks, whole kernel
+    o[2] = (float)(ts_loop - ts_entry);                             // cycles before the loop
+    o[3] = (float)t_wait;                                           // cycles in vmcnt wait + barrier
+    o[4] = (float)n_ph;
   }
 }
 
@@ -658,6 +884,15 @@ __global__ void __launch_bounds__(192) k_pool_norm(const _Float16* __restrict__ 
   }
 }
 
+void* rf_debug_buffer = nullptr;   // rf_debug_set_buffer: clock stamps of the diagnostic runs
+extern "C" int rf_debug_set_buffer(void* dev_ptr) {
+  rf_debug_buffer = dev_ptr;
+  return RF_OK;
+}
+int rf_debug_linear_flags = 0;   // ablation bits of k_linear_dma (rf_set_tuning("linear_dbg", v))
+int rf_debug_epi = 1;   // which k_linear_dma epilogue (0 QKV, 1 FFN1) writes the stamps
+int rf_tuning_linear_dma = 1;   // K = 384 GEMMs with plain epilogues through the LDS-DMA ring (A/B knob)
+
 // ---- forward pass -----------------------------------------------------------------------
 // the LayerNorm-fused GEMMs have only 384 output features (one feature group), so
 // they take 32-token tiles to put twice as many workgroups on the chip
@@ -667,6 +902,18 @@ static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Floa
                           const _Float16* g, const _Float16* b, float eps, hipStream_t st) {
   constexpr int NTB = 2;
   const int tiles = (tokens + 32 * NTB - 1) / (32 * NTB);
+  if (K == 384 && EPI != EPI_BIAS_RES_LN && rf_tuning_linear_dma) {
+    const size_t lds = (size_t)LD_SLOTS * LD_FRAGS * RF_FRAG_BYTES + RF_FRAG_BYTES + (size_t)N * 2;
+    auto kern = k_linear_dma<(EPI == EPI_BIAS_GELU ? EPI_BIAS_GELU : EPI_BIAS)>;
+    static size_t attr = 0;
+    if (lds > attr) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((tokens + LD_TOK - 1) / LD_TOK), dim3(LD_WAVES * 64), lds, st, X, Wt, bias, out,
+                       N, m_ptr, (rf_debug_epi == (int)EPI) ? (float*)rf_debug_buffer : nullptr, rf_debug_linear_flags);
+    return;
+  }
   if (K == 384)
     hipLaunchKernelGGL((k_linear<EPI, NTB, 24>), dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out,
                        N, m_ptr, res, g, b, eps);

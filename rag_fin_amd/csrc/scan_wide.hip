@@ -18,6 +18,7 @@
 // LDS, no barrier; 7 of 8 reads are L1/L2 hits) -- 447 us per 256-query step against
 // 284 us for this form: the 8x load-instruction count saturates the TA path.
 #include "scan_common.h"
+#include "lds_ring.h"
 #include <stdlib.h>
 
 #define WIDE_KS 24
@@ -265,7 +266,6 @@ int rf_launch_wide_emit(const rf_index* ix, const void* q, int B, const rf_works
 #define WL_SLOTS 3
 #define WL_PB 2                               // corpus blocks per phase
 #define WL_FRAGS (WIDE_KS * WL_PB)            // 1-KiB fragments per phase (48)
-#define WL_GRP 4                              // fragments per LDS read group
 #define WL_STAGE_WORDS 3072                   // emit staging, all waves: NW * CAP entries * 3 words
 
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
@@ -283,36 +283,6 @@ __device__ __forceinline__ float max16_v3(const f32x16& a) {
   m = vmax3(m, a[11], a[12]);
   m = vmax3(m, a[13], a[14]);
   return vmax3(m, a[15], a[15]);
-}
-
-// inline-asm LDS fragment reads: `addr` is the lane's byte address of fragment 0 of the slot;
-// fragment f sits 1 KiB * f further on (immediate offset, < 64 KiB)
-template <int F>
-__device__ __forceinline__ void lds_read_frag(u32x4& d, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(F * 1024));
-}
-template <int F0>
-__device__ __forceinline__ void lds_read_group(u32x4 (&d)[WL_GRP], uint32_t addr) {
-  lds_read_frag<F0 + 0>(d[0], addr);
-  lds_read_frag<F0 + 1>(d[1], addr);
-  lds_read_frag<F0 + 2>(d[2], addr);
-  lds_read_frag<F0 + 3>(d[3], addr);
-}
-__device__ __forceinline__ void lds_read_group_dyn(u32x4 (&d)[WL_GRP], uint32_t addr, int f0) {
-  // f0 is a compile-time constant after unrolling; dispatch to the immediate-offset forms
-  switch (f0) {
-#define WL_CASE(x) case x: lds_read_group<x>(d, addr); break;
-    WL_CASE(4) WL_CASE(8) WL_CASE(12) WL_CASE(16) WL_CASE(20) WL_CASE(24) WL_CASE(28) WL_CASE(32)
-    WL_CASE(36) WL_CASE(40) WL_CASE(44)
-#undef WL_CASE
-    default: break;
-  }
-}
-// wait until at most N LDS reads are outstanding; ties the group's registers to the wait so
-// that the MFMAs consuming them cannot be scheduled above it
-template <int N>
-__device__ __forceinline__ void lds_wait_group(u32x4 (&d)[WL_GRP]) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(N));
 }
 
 // ABL: compile-time ablation of the diagnostic builds (tools/bench_wide.py --dbg 8|16|32, results

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--batch-tokens", type=int, default=32768)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--fixed-len", type=int, default=0)
+    ap.add_argument("--stamps", action="store_true", help="clock stamps of the last k_linear_dma launch")
+    ap.add_argument("--stamp-epi", type=int, default=1, help="0 = QKV, 1 = FFN1")
+    ap.add_argument("--linear-dbg", type=int, default=0, help="ablation bits of k_linear_dma (results wrong)")
     args = ap.parse_args()
     import torch
     from oracle import encoder as oenc
@@ -54,6 +57,25 @@ def main():
             out[torch.as_tensor(idx, device=dev)] = emb.encode_ids(ids, ln)
     run()
     torch.cuda.synchronize()
+    if args.stamps:
+        from ctypes import c_void_p
+        from rag_fin_amd import _lib
+        lib = _lib.load_library()
+        buf = torch.zeros(512 * 8 * 8, dtype=torch.float32, device=dev)
+        lib.rf_set_tuning(b"debug_epi", args.stamp_epi)
+        lib.rf_set_tuning(b"linear_dbg", args.linear_dbg)
+        lib.rf_debug_set_buffer(c_void_p(buf.data_ptr()))
+        ids, ln, idx = batches[len(batches) // 2]
+        emb.encode_ids(ids, ln)
+        torch.cuda.synchronize()
+        lib.rf_debug_set_buffer(None)
+        st = buf.view(512, 8, 8).cpu().numpy()
+        ok = st[..., 1] > 0
+        cyc, ticks, pre, wait, nph = (st[..., i][ok] for i in range(5))
+        print("stamps (last k_linear_dma launch of the chosen epilogue, %d waves): clock %.2f GHz; kernel %.1f us; "
+              "prologue %.0f cycles; loop %.0f cycles/phase (%d phases); wait+barrier share %.1f %%" %
+              (ok.sum(), np.median(cyc / ticks) * 0.1, np.median(ticks) / 100.0, np.median(pre),
+               np.median((cyc - pre) / nph), int(nph.max()), 100.0 * np.median(wait / cyc)))
     times = []
     for _ in range(args.iters):
         t = time.perf_counter()

@@ -192,6 +192,25 @@ int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* le
               int B, int T, void* out_f16_dev, float* out_f32_dev,
               void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- tokenizer: the text -> token-id stage in front of rf_encode ------------------------
+ * Reference: the WordPiece tokenizer SentenceTransformer('all-MiniLM-L6-v2') loads by name
+ * (vector_rag_mcp/main.py:41,50; "chunking_storing (1).py":8,380).  Host code, multi-threaded.
+ * ASCII text is tokenised end to end; text with non-ASCII characters must be pre-normalised by
+ * the caller (rag_fin_amd/tokenizer.py does it with Python's unicodedata: clean, NFC, lower,
+ * NFD, strip Mn, CJK / non-ASCII punctuation padded with spaces).
+ * vocab_utf8: the vocabulary file's bytes, one token per line, line i = id i. */
+typedef struct rf_tokenizer rf_tokenizer_t;
+int rf_tokenizer_create(rf_tokenizer_t** out, const char* vocab_utf8, size_t vocab_bytes,
+                        int do_lower_case, int max_chars_per_word);
+int rf_tokenizer_destroy(rf_tokenizer_t* t);
+/* ids5 <- { [UNK], [CLS], [SEP], [PAD], [MASK] (-1 if absent) } */
+int rf_tokenizer_special_ids(const rf_tokenizer_t* t, int32_t* ids5);
+/* text_bytes: the n texts' UTF-8 bytes back to back, text i = [offsets[i], offsets[i+1]).
+ * ids_out int32 [n, max_len] ([CLS] ids [SEP], padded with [PAD]); lens_out int32 [n].
+ * n_threads <= 0: one per hardware thread (at most 64). */
+int rf_tokenize_batch(const rf_tokenizer_t* t, const char* text_bytes, const int64_t* offsets, int n,
+                      int max_len, int32_t* ids_out, int32_t* lens_out, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

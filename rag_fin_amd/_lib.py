@@ -67,6 +67,10 @@ SIGNATURES = {
     "rf_merge_shards": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p]),
     "rf_merge_shards_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rf_tokenizer_create": (c_int, [POINTER(c_void_p), c_char_p, c_size_t, c_int, c_int]),
+    "rf_tokenizer_destroy": (c_int, [c_void_p]),
+    "rf_tokenizer_special_ids": (c_int, [c_void_p, c_void_p]),
+    "rf_tokenize_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
     "rf_set_tuning": (c_int, [c_char_p, c_int]),
     "rf_debug_workspace_offset": (c_size_t, [c_char_p]),
     "rf_debug_set_buffer": (c_int, [c_void_p]),

@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libragfin_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["index.hip", "scan.hip", "scan_fused.hip", "scan_wide.hip", "merge.hip", "api.hip", "encoder.hip"]
+SOURCES = ["index.hip", "scan.hip", "scan_fused.hip", "scan_wide.hip", "merge.hip", "api.hip", "encoder.hip",
+           "tokenizer.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -39,7 +40,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "ragfin.h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    objs = [s[:-4] + ".o" for s in srcs]
+    objs = [os.path.splitext(s)[0] + ".o" for s in srcs]
 
     def compile_one(pair):
         src, obj = pair

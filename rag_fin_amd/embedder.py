@@ -190,23 +190,31 @@ class Embedder:
                                "tokenizer=WordPieceTokenizer(vocab)")
         if isinstance(sentences, str):
             sentences = [sentences]
-        rows = [self.tokenizer.encode(s, self.max_seq_length) for s in sentences]
-        order = sorted(range(len(rows)), key=lambda i: len(rows[i]))
-        out = torch.empty((len(rows), self.dim), dtype=torch.float16, device=self.device)
+        # text -> ids through the native tokenizer (csrc/tokenizer.cpp, one thread per host core);
+        # a tokenizer object without batch_native (a test double) takes the per-sentence path
+        sentences = list(sentences)
+        if hasattr(self.tokenizer, "batch_native"):
+            all_ids, all_lens = self.tokenizer.batch_native(sentences, self.max_seq_length)
+        else:
+            rows = [self.tokenizer.encode(s, self.max_seq_length) for s in sentences]
+            all_lens = np.array([len(r) for r in rows], dtype=np.int32)
+            all_ids = np.full((len(rows), max(int(all_lens.max()), 1) if len(rows) else 1), self.tokenizer.pad_id,
+                              dtype=np.int32)
+            for r, row in enumerate(rows):
+                all_ids[r, :len(row)] = row
+        n = len(sentences)
+        order = np.argsort(all_lens, kind="stable")
+        out = torch.empty((n, self.dim), dtype=torch.float16, device=self.device)
         i = 0
-        while i < len(order):
-            T = len(rows[order[i]])
+        while i < n:
             j = i
             # rows are sorted ascending, so the last row of a bucket sets its width
-            while j < len(order) and (j - i + 1) * len(rows[order[j]]) <= max(batch_tokens, len(rows[order[j]])):
-                T = len(rows[order[j]])
+            while j < n and (j - i + 1) * int(all_lens[order[j]]) <= max(batch_tokens, int(all_lens[order[j]])):
                 j += 1
             idx = order[i:j]
-            ids = np.full((len(idx), T), self.tokenizer.pad_id, dtype=np.int32)
-            lens = np.empty(len(idx), dtype=np.int32)
-            for r, k in enumerate(idx):
-                ids[r, :len(rows[k])] = rows[k]
-                lens[r] = len(rows[k])
+            T = int(all_lens[idx[-1]])
+            ids = np.ascontiguousarray(all_ids[idx, :T])
+            lens = np.ascontiguousarray(all_lens[idx])
             out[torch.as_tensor(idx, device=self.device)] = self.encode_ids(ids, lens)
             i = j
         return out

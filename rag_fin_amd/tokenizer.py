@@ -36,6 +36,33 @@ def _is_cjk(cp: int) -> bool:
             or 0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
 
 
+class _LazyTable(dict):
+    """str.translate table that classifies a code point the first time it is seen."""
+
+    def __init__(self, fn):
+        super().__init__()
+        self._fn = fn
+
+    def __missing__(self, cp):
+        v = self._fn(cp)
+        self[cp] = v
+        return v
+
+
+def _clean_map(cp: int):
+    """_clean() for one code point (ASCII is left to the C++ side)."""
+    if cp < 128:
+        return cp
+    ch = chr(cp)
+    if cp == 0xFFFD or _is_control(ch):
+        return None
+    if _is_cjk(cp):
+        return " " + ch + " "
+    if _is_whitespace(ch):
+        return " "
+    return cp
+
+
 class WordPieceTokenizer:
     def __init__(self, vocab: dict[str, int] | Iterable[str], do_lower_case: bool = True,
                  unk_token: str = "[UNK]", cls_token: str = "[CLS]", sep_token: str = "[SEP]",
@@ -130,6 +157,83 @@ class WordPieceTokenizer:
             ids.extend(self.wordpiece(w) if w not in self.special else [self.vocab[w]])
         ids = ids[:max(0, max_length - 2)]
         return [self.cls_id] + ids + [self.sep_id]
+
+    # -- native path (libragfin_hip.so: csrc/tokenizer.cpp, multi-threaded) ---------------
+    # The C++ tokenizer applies the ASCII rules; text with non-ASCII characters is first
+    # brought to a form in which those rules are all that is left to apply, using only
+    # C-speed string primitives (translate with lazily built tables, normalize, lower).
+    def _native(self):
+        if getattr(self, "_nat", None) is None:
+            from ctypes import byref, c_void_p
+            from . import _lib
+            lib = _lib.load_library()
+            toks = [None] * (max(self.vocab.values()) + 1)
+            for t, i in self.vocab.items():
+                toks[i] = t
+            blob = "\n".join("" if t is None else t for t in toks).encode("utf-8")
+            h = c_void_p()
+            _lib.check(lib.rf_tokenizer_create(byref(h), blob, len(blob), 1 if self.do_lower_case else 0,
+                                               self.max_chars))
+            self._nat = (lib, h)
+            self._clean_tab = _LazyTable(_clean_map)
+            self._mn_tab = _LazyTable(lambda cp: None if unicodedata.category(chr(cp)) == "Mn" else cp)
+            self._mn_punct_tab = _LazyTable(lambda cp: None if unicodedata.category(chr(cp)) == "Mn" else
+                                            (" " + chr(cp) + " " if cp >= 128 and
+                                             unicodedata.category(chr(cp)).startswith("P") else cp))
+            self._punct_tab = _LazyTable(lambda cp: " " + chr(cp) + " " if cp >= 128 and
+                                         unicodedata.category(chr(cp)).startswith("P") else cp)
+        return self._nat
+
+    def _prenormalise(self, text: str):
+        """Non-ASCII text -> a string on which the ASCII rules of the C++ tokenizer give the
+        tokens of basic_tokens(); None when the text must take the Python path (it contains a
+        literal special token, which whole-string lower-casing would destroy)."""
+        s = text.translate(self._clean_tab)
+        if not unicodedata.is_normalized("NFC", s):
+            s = unicodedata.normalize("NFC", s)
+        if "[" in s and any(sp in s for sp in self.special):
+            return None
+        if self.do_lower_case:
+            s = s.lower()
+            if not unicodedata.is_normalized("NFD", s):
+                s = unicodedata.normalize("NFD", s)
+            return s.translate(self._mn_punct_tab)   # strip Mn and pad punctuation in one pass
+        return s.translate(self._punct_tab)
+
+    def batch_native(self, texts: list[str], max_length: int = 256, n_threads: int = 0):
+        """Same result as batch(), through rf_tokenize_batch.  -> (ids int32 [B, T], lens int32 [B])."""
+        import numpy as np
+        from ctypes import c_void_p
+        from . import _lib
+        lib, h = self._native()
+        n = len(texts)
+        if n == 0:
+            return np.full((0, 1), self.pad_id, dtype=np.int32), np.zeros((0,), dtype=np.int32)
+        enc, python_rows = [], {}
+        for i, t in enumerate(texts):
+            if not t.isascii():
+                t = self._prenormalise(t)
+                if t is None:
+                    python_rows[i] = self.encode(texts[i], max_length)
+                    t = ""
+            try:
+                enc.append(t.encode("utf-8"))
+            except UnicodeEncodeError:           # lone surrogates: Python path
+                python_rows[i] = self.encode(texts[i], max_length)
+                enc.append(b"")
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in enc], out=offsets[1:])
+        blob = b"".join(enc)
+        ids = np.empty((n, max_length), dtype=np.int32)
+        lens = np.empty((n,), dtype=np.int32)
+        _lib.check(lib.rf_tokenize_batch(h, blob, c_void_p(offsets.ctypes.data), n, max_length,
+                                         c_void_p(ids.ctypes.data), c_void_p(lens.ctypes.data), n_threads))
+        for i, row in python_rows.items():
+            ids[i, :] = self.pad_id
+            ids[i, :len(row)] = row
+            lens[i] = len(row)
+        T = max(int(lens.max()), 1)
+        return np.ascontiguousarray(ids[:, :T]), lens
 
     def batch(self, texts: list[str], max_length: int = 256):
         """-> (ids int32 [B, T] padded with [PAD], lens int32 [B]), T = longest row."""

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batch-tokens", type=int, default=32768)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--fixed-len", type=int, default=0)
+    ap.add_argument("--texts", action="store_true", help="also time the text -> tokenizer -> encoder path")
     ap.add_argument("--stamps", action="store_true", help="clock stamps of the last k_linear_dma launch")
     ap.add_argument("--stamp-epi", type=int, default=1, help="0 = QKV, 1 = FFN1")
     ap.add_argument("--linear-dbg", type=int, default=0, help="ablation bits of k_linear_dma (results wrong)")
@@ -93,7 +94,41 @@ def main():
         ix.search_raw(q, 10)
     torch.cuda.synchronize()
     search_ms = (time.perf_counter() - t) / 50 * 1e3
+    text_leg = None
+    if args.texts:
+        # end-to-end from TEXT: chunk texts re-templated from the 16 golden chunks with perturbed
+        # figures, vocabulary built from their words (no real vocab offline),
+        # native tokenizer -> bucketed encode -> search
+        import re
+        from rag_fin_amd.tokenizer import WordPieceTokenizer
+        gold = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                           "tests", "golden", "chunks_golden.json")))
+        base = [c["text"] for c in gold]
+        trng = np.random.default_rng(11)
+        texts = [re.sub(r"\d", lambda m: str(int(trng.integers(0, 10))), base[i % len(base)]) for i in range(args.chunks)]
+        words = set()
+        for t in base:
+            words.update(re.findall(r"[a-z]+|[0-9]|[^\sa-z0-9]", t.lower()))
+        vocab = (["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + sorted(words) +
+                 ["##" + w for w in sorted(words) if w.isalpha()] + ["##%d" % i for i in range(10)])
+        vocab = list(dict.fromkeys(vocab)) + ["[unused%d]" % i for i in range(cfg["vocab_size"])]
+        emb_t = Embedder(oenc.random_weights(cfg, 0), cfg, tokenizer=WordPieceTokenizer(vocab[:cfg["vocab_size"]]),
+                         device=dev)
+        emb_t.encode_to_device(texts[:256])
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ids_, lens_ = emb_t.tokenizer.batch_native(texts, 256)
+        tok_s = time.perf_counter() - t
+        t = time.perf_counter()
+        e_ = emb_t.encode_to_device(texts, batch_tokens=args.batch_tokens)
+        torch.cuda.synchronize()
+        e2e_s = time.perf_counter() - t
+        text_leg = {"texts": len(texts), "tokens": int(lens_.sum()), "tokenize_s": round(tok_s, 4),
+                    "tokenize_texts_per_s": round(len(texts) / tok_s, 1),
+                    "text_to_embedding_s": round(e2e_s, 4), "texts_per_s": round(len(texts) / e2e_s, 1),
+                    "host_threads": len(os.sched_getaffinity(0))}
     print(json.dumps({"workload": f"encode {args.chunks} chunks (lens U[40,250]) + top-10 search, MiniLM-L6 random weights",
+                      "from_text": text_leg,
                       "chunks": args.chunks, "tokens": tokens, "batches": len(batches),
                       "encode_s": round(best, 4), "tokens_per_s": round(tokens / best, 1),
                       "chunks_per_s": round(args.chunks / best, 1),

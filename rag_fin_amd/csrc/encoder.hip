@@ -129,6 +129,7 @@ extern "C" int rf_encoder_destroy(rf_encoder_t* enc) {
   return RF_OK;
 }
 
+#define SM_MAX_TOK 1024   // token slots (B * T) up to which the small-batch GEMM path is taken
 // ---- workspace ---------------------------------------------------------------------
 struct EncWs {
   int32_t* tok_off;   // [B + 1]
@@ -137,6 +138,7 @@ struct EncWs {
   _Float16* qkv;      // [Mpad, 1152]
   _Float16* ctx;      // [Mpad, 384]
   _Float16* ff;       // [Mpad, I]
+  float* pre;         // [min(Mpad, SM_MAX_TOK), 384] fp32: pre-LayerNorm sums of the small-batch path
 };
 
 static size_t enc_carve(unsigned char* base, int B, int T, int I, EncWs* ws) {
@@ -153,7 +155,8 @@ static size_t enc_carve(unsigned char* base, int B, int T, int I, EncWs* ws) {
   _Float16* qkv = (_Float16*)take(Mpad * 3 * HID * 2);
   _Float16* ctx = (_Float16*)take(Mpad * HID * 2);
   _Float16* ff = (_Float16*)take(Mpad * (size_t)I * 2);
-  if (ws) *ws = EncWs{tok, x, y, qkv, ctx, ff};
+  float* pre = (float*)take((Mpad < SM_MAX_TOK ? Mpad : (size_t)SM_MAX_TOK) * HID * 4);
+  if (ws) *ws = EncWs{tok, x, y, qkv, ctx, ff, pre};
   return off;
 }
 
@@ -645,6 +648,145 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
   }
 }
 
+// ---- small batches (a single query: the reference's only serving mode) -------------------
+// With a handful of tokens the GEMMs above are latency chains: one 64/128-token tile means one
+// workgroup per 384 (or all N) features streaming 0.3-1.2 MB of weights through ONE CU --
+// 9-45 us per call, 620 us per 6-layer forward of a 12-token query.  k_linear_small spreads
+// the OUTPUT FEATURES over the chip instead: a workgroup owns 32 features x 64 tokens, its four
+// waves split the K range (6 or 24 k-steps each, every load issued before the first MFMA),
+// partial sums meet in LDS.  N/32 = 36 / 12 / 48 / 12 workgroups per call, each reading 24-96 KB.
+// The LayerNorm epilogues need all 384 features of a token, which no longer meet in one
+// workgroup: the GEMM writes bias + residual sums as fp32 rows and k_ln_rows (one wave per
+// token) normalises them -- same arithmetic (fp32 statistics of the fp32 sums), one more launch.
+enum { EPI_PRE_LN = 3 };   // bias + residual -> fp32 [token][384] row-major scratch
+#define SM_TOK 64
+template <int EPI, int KS>
+__global__ void __launch_bounds__(256) k_linear_small(
+    const _Float16* __restrict__ X, const uint4* __restrict__ Wt, const _Float16* __restrict__ bias,
+    _Float16* __restrict__ out, float* __restrict__ pre, int N, const int32_t* __restrict__ m_ptr,
+    const _Float16* __restrict__ res) {
+  constexpr int KW = KS / 4;   // k-steps per wave
+  __shared__ float red[4][2][16][64];   // [wave][token block][register][lane]: 32 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int fblk = blockIdx.x;
+  const int t0 = blockIdx.y * SM_TOK;
+  // every load of this wave's K range goes out before anything else (KW = 6: 18 loads; 24: in 3 rounds of 8)
+  const uint4* wsrc = Wt + ((size_t)fblk * KS + wave * KW) * 64 + lane;
+  const _Float16* xsrc = X + (((size_t)(t0 >> 5) * KS + wave * KW) * 64 + lane) * 8;
+  f32x16 acc[2];
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[tb][i] = 0.f;
+  constexpr int RND = KW < 8 ? KW : 8;
+#pragma unroll
+  for (int r0 = 0; r0 < KW; r0 += RND) {
+    uint4 wf[RND];
+    half8 xf[RND][2];
+#pragma unroll
+    for (int r = 0; r < RND; ++r) {
+      wf[r] = wsrc[(size_t)(r0 + r) * 64];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) xf[r][tb] = *(const half8*)(xsrc + ((size_t)tb * KS + r0 + r) * 512);
+    }
+#pragma unroll
+    for (int r = 0; r < RND; ++r)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+        acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wf[r]), xf[r][tb], acc[tb], 0, 0, 0);
+  }
+  const int M = *m_ptr;
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][tb][i][lane] = acc[tb][i];
+  __syncthreads();
+  // wave w finishes token block w >> 1, registers 8 (w & 1) .. +8 (two groups of 4 features)
+  const int tb = wave >> 1;
+  const int token = t0 + tb * 32 + c;
+#pragma unroll
+  for (int gg = 0; gg < 2; ++gg) {
+    const int g = 2 * (wave & 1) + gg;
+    const int f = fblk * 32 + 8 * g + 4 * h;   // first of the lane's 4 consecutive features
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * g + j;
+      v[j] = (red[0][tb][i][lane] + red[1][tb][i][lane]) + (red[2][tb][i][lane] + red[3][tb][i][lane]);
+    }
+    const half4 bv = *(const half4*)(bias + f);
+    if (EPI == EPI_PRE_LN) {
+      if (token < M) {
+        const half4 rv = *(const half4*)(res + toff(token, f, HID / 16));
+        float4 o;
+        o.x = v[0] + (float)bv[0] + (float)rv[0];
+        o.y = v[1] + (float)bv[1] + (float)rv[1];
+        o.z = v[2] + (float)bv[2] + (float)rv[2];
+        o.w = v[3] + (float)bv[3] + (float)rv[3];
+        *(float4*)(pre + (size_t)token * HID + f) = o;
+      }
+    } else {
+      half4 o;
+      if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          f32x2 y;
+          y[0] = v[j] + (float)bv[j];
+          y[1] = v[j + 1] + (float)bv[j + 1];
+          y = gelu_erf2(y);
+          o[j] = (_Float16)y[0];
+          o[j + 1] = (_Float16)y[1];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (_Float16)(v[j] + (float)bv[j]);
+      }
+      if (token < M) *(half4*)(out + toff(token, f, N / 16)) = o;
+    }
+  }
+}
+
+// LayerNorm of fp32 rows [token][384] -> fp16 tiled activations; one wave per token
+__global__ void __launch_bounds__(256) k_ln_rows(const float* __restrict__ pre, const int32_t* __restrict__ m_ptr,
+                                                 const _Float16* __restrict__ gamma,
+                                                 const _Float16* __restrict__ beta, float eps,
+                                                 _Float16* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int token = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (token >= *m_ptr) return;
+  // lane l < 48 owns features 8 l .. 8 l + 7
+  float v[8];
+  if (lane < 48) {
+    const float4 a = *(const float4*)(pre + (size_t)token * HID + lane * 8);
+    const float4 b = *(const float4*)(pre + (size_t)token * HID + lane * 8 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += v[j];
+  const float mu = wave_sum(s) * (1.f / HID);
+  float q = 0.f;
+  if (lane < 48) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q += (v[j] - mu) * (v[j] - mu);
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.f / HID) + eps);
+  if (lane < 48) {
+    const half8 gg = *(const half8*)(gamma + lane * 8);
+    const half8 bb = *(const half8*)(beta + lane * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)((v[j] - mu) * rstd * (float)gg[j] + (float)bb[j]);
+    *(half8*)(out + toff(token, lane * 8, HID / 16)) = o;
+  }
+}
+
 // Attention on the matrix cores for sequences of <= 256 tokens (the model's
 // max_seq_length): one workgroup per (sequence, head); K rows and V^T in LDS.
 //   S^T = K Q^T   A = 32 keys (LDS rows padded to 80 B: conflict-free b128 reads),
@@ -891,6 +1033,7 @@ extern "C" int rf_debug_set_buffer(void* dev_ptr) {
 }
 int rf_debug_linear_flags = 0;   // ablation bits of k_linear_dma (rf_set_tuning("linear_dbg", v))
 int rf_debug_epi = 1;   // which k_linear_dma epilogue (0 QKV, 1 FFN1) writes the stamps
+int rf_tuning_linear_small = 1;   // B * T <= SM_MAX_TOK: feature-split GEMMs + separate LayerNorm (A/B knob)
 int rf_tuning_linear_dma = 1;   // K = 384 GEMMs with plain epilogues through the LDS-DMA ring (A/B knob)
 
 // ---- forward pass -----------------------------------------------------------------------
@@ -899,10 +1042,22 @@ int rf_tuning_linear_dma = 1;   // K = 384 GEMMs with plain epilogues through th
 template <int EPI>
 static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Float16* bias,
                           _Float16* out, int N, int tokens, const int32_t* m_ptr, const _Float16* res,
-                          const _Float16* g, const _Float16* b, float eps, hipStream_t st) {
+                          const _Float16* g, const _Float16* b, float eps, float* pre, hipStream_t st) {
   constexpr int NTB = 2;
   const int tiles = (tokens + 32 * NTB - 1) / (32 * NTB);
-  if (K == 384 && EPI != EPI_BIAS_RES_LN && rf_tuning_linear_dma) {
+  if (tokens <= SM_MAX_TOK && rf_tuning_linear_small) {
+    // small batches: output features spread over the chip (k_linear_small), LayerNorm as its own launch
+    const dim3 grid(N / 32, (tokens + SM_TOK - 1) / SM_TOK);
+    constexpr int E = (EPI == EPI_BIAS_RES_LN) ? (int)EPI_PRE_LN : (int)EPI;
+    if (K == 384)
+      hipLaunchKernelGGL((k_linear_small<E, 24>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res);
+    else
+      hipLaunchKernelGGL((k_linear_small<E, 96>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res);
+    if (EPI == EPI_BIAS_RES_LN)
+      hipLaunchKernelGGL(k_ln_rows, dim3((tokens + 3) / 4), dim3(256), 0, st, pre, m_ptr, g, b, eps, out);
+    return;
+  }
+  if (K == 384 && EPI != EPI_BIAS_RES_LN && rf_tuning_linear_dma && tokens >= 8192) {
     const size_t lds = (size_t)LD_SLOTS * LD_FRAGS * RF_FRAG_BYTES + RF_FRAG_BYTES + (size_t)N * 2;
     auto kern = k_linear_dma<(EPI == EPI_BIAS_GELU ? EPI_BIAS_GELU : EPI_BIAS)>;
     static size_t attr = 0;
@@ -982,7 +1137,7 @@ extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const 
     const uint4* ff1_t = enc->ff1_t + (size_t)l * I * HID / 8;
     const uint4* ff2_t = enc->ff2_t + (size_t)l * HID * I / 8;
     launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
-                            3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, st);
+                            3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
     if (T <= 32 * ATT_MAX_KB)
       hipLaunchKernelGGL(k_attention_mfma, dim3(B, c.heads / ATT_HEADS), dim3(256), mfma_lds, st, ws.qkv,
                          ws.tok_off, ws.ctx);
@@ -991,12 +1146,12 @@ extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const 
                          ws.ctx);
     launch_linear<EPI_BIAS_RES_LN>(ws.ctx, HID, ao_t, (const _Float16*)w.ao_b + (size_t)l * HID, y, HID,
                                    tiles, m_ptr, x, (const _Float16*)w.ln1_g + (size_t)l * HID,
-                                   (const _Float16*)w.ln1_b + (size_t)l * HID, c.ln_eps, st);
+                                   (const _Float16*)w.ln1_b + (size_t)l * HID, c.ln_eps, ws.pre, st);
     launch_linear<EPI_BIAS_GELU>(y, HID, ff1_t, (const _Float16*)w.ff1_b + (size_t)l * I, ws.ff, I,
-                                 tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, st);
+                                 tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
     launch_linear<EPI_BIAS_RES_LN>(ws.ff, I, ff2_t, (const _Float16*)w.ff2_b + (size_t)l * HID, x, HID,
                                    tiles, m_ptr, y, (const _Float16*)w.ln2_g + (size_t)l * HID,
-                                   (const _Float16*)w.ln2_b + (size_t)l * HID, c.ln_eps, st);
+                                   (const _Float16*)w.ln2_b + (size_t)l * HID, c.ln_eps, ws.pre, st);
   }
   hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(192), 0, st, x, ws.tok_off, (_Float16*)out_f16_dev,
                      out_f32_dev);

@@ -321,7 +321,7 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t st) {
 
 // ---- tuning knobs (rf_set_tuning / environment at first use) ---------------------------
 extern int rf_tuning_fused;  // api.hip
-extern int rf_tuning_linear_dma, rf_debug_epi, rf_debug_linear_flags;   // encoder.hip
+extern int rf_tuning_linear_dma, rf_tuning_linear_small, rf_debug_epi, rf_debug_linear_flags;   // encoder.hip
 extern int rf_tuning_wide_variant, rf_tuning_wide_nt, rf_tuning_wide_dbg, rf_tuning_wide_sample_pairs;  // scan_wide.hip
 struct ScanTuning {
   int ring24;           // register-ring depth (fragments) of the dim-384 kernels: 6 | 8 | 12 | 24
@@ -346,6 +346,7 @@ extern "C" int rf_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "sample_bpw") && value >= 1 && value <= 8) t.sample_bpw = value;
   else if (!strcmp(key, "qreg") && (value == 0 || value == 1)) t.qreg = value;
   else if (!strcmp(key, "linear_dma") && (value == 0 || value == 1)) rf_tuning_linear_dma = value;
+  else if (!strcmp(key, "linear_small") && (value == 0 || value == 1)) rf_tuning_linear_small = value;
   else if (!strcmp(key, "linear_dbg") && value >= 0 && value <= 15) rf_debug_linear_flags = value;
   else if (!strcmp(key, "debug_epi") && (value == 0 || value == 1)) rf_debug_epi = value;
   else if (!strcmp(key, "fused") && (value == 0 || value == 1)) rf_tuning_fused = value;

@@ -108,3 +108,47 @@ def test_text_encode_end_to_end_with_synthetic_vocab(gpu_device):
     assert np.abs(got - want).max() < TOL + 1e-3
     one = emb.encode(texts[5])
     assert one.shape == (384,) and np.abs(one - got[5]).max() < 2e-3
+
+
+def test_all_gemm_paths_agree_and_match_the_oracle(gpu_device):
+    """The encoder has three GEMM paths chosen by batch size -- feature-split + separate
+    LayerNorm (<= 1024 token slots), direct-load tiles, and weights through the LDS-DMA ring
+    (>= 8192 slots, QKV / FFN1).  A 10 240-slot batch is run through the two large-batch
+    paths, a 512-slot batch through small and direct; outputs must agree with each other
+    to fp16 resolution and with the numpy oracle (2 layers, checked on a row subset)."""
+    from rag_fin_amd import _lib
+    from rag_fin_amd.embedder import Embedder
+    lib = _lib.load_library()
+    cfg = dict(oenc.MINILM_L6, layers=2, vocab_size=3000)
+    w = oenc.random_weights(cfg, 11)
+    emb = Embedder(w, cfg, device=gpu_device)
+    rng = np.random.default_rng(3)
+
+    def enc(ids, lens, **knobs):
+        try:
+            for k, v in knobs.items():
+                _lib.check(lib.rf_set_tuning(k.encode(), v))
+            return emb.encode_ids(ids, lens, out_dtype="float32").cpu().numpy()
+        finally:
+            for k in knobs:
+                lib.rf_set_tuning(k.encode(), 1)
+
+    B, T = 40, 256                                   # 10 240 slots: LDS-DMA ring by default
+    lens = rng.integers(30, T + 1, B).astype(np.int32)
+    lens[0] = T
+    ids = rng.integers(1, 3000, (B, T)).astype(np.int32)
+    dma = enc(ids, lens)
+    direct = enc(ids, lens, linear_dma=0)
+    assert np.abs(dma - direct).max() < 2e-3
+    sub = [0, 1, 7, 39]
+    want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids[sub], lens[sub])
+    assert np.abs(dma[sub] - want).max() < TOL and np.abs(direct[sub] - want).max() < TOL
+
+    B, T = 8, 64                                     # 512 slots: small-batch path by default
+    lens = rng.integers(1, T + 1, B).astype(np.int32)
+    ids = rng.integers(1, 3000, (B, T)).astype(np.int32)
+    small = enc(ids, lens)
+    direct = enc(ids, lens, linear_small=0)
+    want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids, lens)
+    assert np.abs(small - direct).max() < 2e-3
+    assert np.abs(small - want).max() < TOL and np.abs(direct - want).max() < TOL

@@ -798,6 +798,11 @@ __global__ void __launch_bounds__(256) k_ln_rows(const float* __restrict__ pre, 
 //                 16s + 8(j>>2) + 4h + (j&3); cdna_hip_programming.md section 3), and V^T
 //                 rows (stride T+4 halfs: conflict-free b64 reads) supply the A operand in
 //                 the same key order.
+__device__ __forceinline__ float att_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 #define ATT_MAX_KB 8
 #define ATT_HEADS 2   // heads per workgroup (12 heads -> grid.y = 6)
 __global__ void __launch_bounds__(256, 2) k_attention_mfma(const _Float16* __restrict__ qkv,
@@ -872,26 +877,37 @@ __global__ void __launch_bounds__(256, 2) k_attention_mfma(const _Float16* __res
           for (int i = 0; i < 16; ++i)
             if (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= n) acc[i] = -INFINITY;
         }
+        // running maximum by v_max3_f32 (two new elements per instruction)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[i]);
+        for (int i = 0; i < 16; i += 2) m = att_max3(m, acc[i], acc[i + 1]);
         sc[kb] = acc;
       }
     }
     m = fmaxf(m, __shfl_xor(m, 32));
-    float l = 0.f;
+    f32x2 l2 = {0.f, 0.f};
     const float c2 = scale * 1.4426950408889634f;   // exp(scale * (s - m)) = exp2(c2 * s - c2 * m)
     const float mc = m * c2;
 #pragma unroll
     for (int kb = 0; kb < ATT_MAX_KB; ++kb) {
       if (kb < nkb) {
+        // exponent argument and row sum on PAIRS (v_pk_fma_f32 / v_pk_add_f32: two floats per
+        // lane at the single rate); v_exp_f32 is the transcendental pipe either way
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(sc[kb][i], c2, -mc));
-          sc[kb][i] = pr;
-          l += pr;
+        for (int i = 0; i < 16; i += 2) {
+          f32x2 e;
+          e[0] = sc[kb][i];
+          e[1] = sc[kb][i + 1];
+          e = __builtin_elementwise_fma(e, f32x2{c2, c2}, f32x2{-mc, -mc});
+          f32x2 pr;
+          pr[0] = __builtin_amdgcn_exp2f(e[0]);
+          pr[1] = __builtin_amdgcn_exp2f(e[1]);
+          sc[kb][i] = pr[0];
+          sc[kb][i + 1] = pr[1];
+          l2 += pr;
         }
       }
     }
+    float l = l2[0] + l2[1];
     l += __shfl_xor(l, 32);
     f32x16 o;
 #pragma unroll

@@ -62,10 +62,17 @@ class VectorRAG:
 
     def search(self, query: str, top_k: int = 3) -> list[dict]:
         """Ranked context dicts, keys exactly as vector_rag_mcp/main.py:59-70."""
-        q = self.similarity_model.encode([query])
+        q = self._embed([query])
         results = self.collection.search(q, "embedding", {"metric_type": "COSINE"}, top_k,
                                          output_fields=OUTPUT_FIELDS)
         return self._contexts(results[0])
+
+    def _embed(self, texts):
+        """`.encode(texts)` of the reference (main.py:50) -- kept on the device when the embedder
+        offers it: the unit-norm fp16 rows rf_encode writes are exactly what the store searches
+        with, so the download / re-upload / re-normalise round trip of the numpy form is skipped."""
+        to_dev = getattr(self.similarity_model, "encode_to_device", None)
+        return to_dev(texts) if to_dev is not None else self.similarity_model.encode(texts)
 
     retrieve = search  # BASELINE.json's "retrieve(query, k)" name for the same call
 
@@ -74,7 +81,7 @@ class VectorRAG:
         is strictly one query per call)."""
         if not queries:
             return []
-        q = self.similarity_model.encode(list(queries))
+        q = self._embed(list(queries))
         results = self.collection.search(q, "embedding", {"metric_type": "COSINE"}, top_k,
                                          output_fields=OUTPUT_FIELDS)
         return [self._contexts(r) for r in results]

@@ -73,6 +73,7 @@ class GpuIndex:
             self.workspace = torch.zeros(ws, dtype=torch.uint8, device=self.device)
             self.workspace_bytes = ws
         self._lock = threading.Lock()
+        self._host_bufs = {}
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -240,6 +241,32 @@ class GpuIndex:
                     exact[bad] = e2
         return scores, ids, exact
 
+    def search_host(self, q16, k: int):
+        """search() whose results land on the host with ONE synchronisation: scores, ids and
+        flags are copied into cached pinned buffers asynchronously.  -> (scores f32 [B,k],
+        ids i64 [B,k]) numpy views (valid until the next call with the same shape)."""
+        torch = _torch()
+        with self._lock:
+            scores, ids, _, flags = self.search_raw(q16, k)
+            B = scores.shape[0]
+            key = (B, k)
+            bufs = self._host_bufs.get(key)
+            if bufs is None:
+                bufs = self._host_bufs[key] = (torch.empty((B, k), dtype=torch.float32, pin_memory=True),
+                                               torch.empty((B, k), dtype=torch.int64, pin_memory=True),
+                                               torch.empty((B,), dtype=torch.int32, pin_memory=True))
+            bufs[0].copy_(scores, non_blocking=True)
+            bufs[1].copy_(ids, non_blocking=True)
+            bufs[2].copy_(flags, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            if bool(bufs[2].any()):
+                bad = torch.nonzero(bufs[2] != 0).flatten()
+                qb = q16.to(self.device)[bad.to(self.device)].contiguous()
+                s2, i2, _ = self.search_exhaustive(qb, k)
+                bufs[0][bad] = s2.cpu()
+                bufs[1][bad] = i2.cpu()
+        return bufs[0].numpy(), bufs[1].numpy()
+
     def debug_scores(self, q16, n: int | None = None):
         torch = _torch()
         n = self.size if n is None else n
@@ -389,10 +416,11 @@ class CorpusStore:
         q16 = self._prepare_queries(data)
         if limit > _lib.RF_MAX_K:
             scores, rows = self.index.search_large(q16, limit)   # paged, exhaustive beyond 64
-        else:
-            scores, rows, _ = self.index.search(q16, limit)
+            kk = min(limit, self.num_entities)
+            return scores[:, :kk].cpu().numpy(), rows[:, :kk].cpu().numpy()
+        scores, rows = self.index.search_host(q16, limit)   # one synchronisation for the whole download
         kk = min(limit, self.num_entities)
-        return scores[:, :kk].cpu().numpy(), rows[:, :kk].cpu().numpy()
+        return scores[:, :kk].copy(), rows[:, :kk].copy()
 
     def search(self, data, anns_field: str = "embedding", param: dict | None = None,
                limit: int = 3, expr=None, output_fields: Iterable[str] | None = None):

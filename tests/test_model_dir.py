@@ -1,0 +1,106 @@
+"""`Embedder.from_local(dir)` -- the replacement for SentenceTransformer('all-MiniLM-L6-v2')
+(vector_rag_mcp/main.py:41) -- against the library stack the reference's model wraps:
+a directory written by transformers (`BertModel.save_pretrained`: config.json +
+model.safetensors, plus vocab.txt and sentence_bert_config.json) with SEEDED RANDOM weights of
+the all-MiniLM-L6-v2 architecture (the real checkpoint is fetched by name in the reference and
+exists nowhere offline).
+
+CPU part: the loader's tensor-name mapping / stacking.  GPU part: text -> embedding through
+from_local().encode() against transformers' BertTokenizer + BertModel + mean-pool +
+L2-normalise on the same texts (fp32 on the host)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TEXTS = ["What was the total income in Q1 2024?", "Net profit rose 12.5% year over year.",
+         "capital adequacy ratio", "Gross NPA • provisions ₹1,234.50 crore",
+         "retail banking segment results for the quarter ended June 30, 2023"]
+
+
+def _make_dir(tmp_path, layers=2):
+    torch = pytest.importorskip("torch")
+    transformers = pytest.importorskip("transformers")
+    chunks = json.load(open(os.path.join(HERE, "golden", "chunks_golden.json")))
+    words = set()
+    for t in [c["text"] for c in chunks] + TEXTS:
+        words.update(re.findall(r"[a-z]+|[0-9]|[^\sa-z0-9]", t.lower()))
+    vocab = list(dict.fromkeys(["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + sorted(words) +
+                               ["##" + w for w in sorted(words) if w.isalpha()] + ["##%d" % i for i in range(10)]))
+    cfg = transformers.BertConfig(vocab_size=len(vocab), hidden_size=384, num_hidden_layers=layers,
+                                  num_attention_heads=12, intermediate_size=1536, max_position_embeddings=512,
+                                  type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu",
+                                  hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(7)
+    model = transformers.BertModel(cfg, add_pooling_layer=False).eval()
+    with torch.no_grad():   # the default init (std 0.02) makes a nearly linear net: widen it
+        for n_, p_ in model.named_parameters():
+            if "LayerNorm" not in n_:
+                p_.mul_(2.5)
+    d = str(tmp_path / "minilm")
+    model.save_pretrained(d, safe_serialization=True)
+    with open(os.path.join(d, "vocab.txt"), "w", encoding="utf-8") as f:
+        f.write("\n".join(vocab) + "\n")
+    with open(os.path.join(d, "sentence_bert_config.json"), "w") as f:
+        json.dump({"max_seq_length": 256, "do_lower_case": False}, f)
+    return d, model, vocab
+
+
+def test_loader_maps_and_stacks_every_tensor(tmp_path):
+    from safetensors.numpy import load_file
+    from rag_fin_amd.embedder import stack_hf_state_dict
+    d, model, vocab = _make_dir(tmp_path)
+    assert os.path.exists(os.path.join(d, "model.safetensors")) and os.path.exists(os.path.join(d, "config.json"))
+    hc = json.load(open(os.path.join(d, "config.json")))
+    cfg = dict(vocab_size=hc["vocab_size"], hidden=hc["hidden_size"], layers=hc["num_hidden_layers"],
+               heads=hc["num_attention_heads"], intermediate=hc["intermediate_size"],
+               max_position=hc["max_position_embeddings"], type_vocab=hc["type_vocab_size"],
+               ln_eps=hc["layer_norm_eps"])
+    w = stack_hf_state_dict(load_file(os.path.join(d, "model.safetensors")), cfg)
+    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    L = cfg["layers"]
+    assert w["word_emb"].shape == (len(vocab), 384) and w["qkv_w"].shape == (L, 1152, 384)
+    assert w["ff1_w"].shape == (L, 1536, 384) and w["ff2_w"].shape == (L, 384, 1536)
+    for l in range(L):
+        p = f"encoder.layer.{l}."
+        assert np.array_equal(w["qkv_w"][l][384:768], sd[p + "attention.self.key.weight"])
+        assert np.array_equal(w["qkv_b"][l][768:], sd[p + "attention.self.value.bias"])
+        assert np.array_equal(w["ao_w"][l], sd[p + "attention.output.dense.weight"])
+        assert np.array_equal(w["ln2_g"][l], sd[p + "output.LayerNorm.weight"])
+    # every checkpoint tensor is consumed exactly once
+    consumed = sum(v.size for v in w.values())
+    assert consumed == sum(v.size for k, v in sd.items() if "position_ids" not in k and "token_type_ids" not in k)
+
+
+@pytest.mark.gpu
+def test_from_local_text_to_embedding_matches_transformers(tmp_path, gpu_device):
+    import torch
+    import transformers
+    from rag_fin_amd.embedder import Embedder
+    d, model, vocab = _make_dir(tmp_path, layers=6)
+    chunks = json.load(open(os.path.join(HERE, "golden", "chunks_golden.json")))
+    texts = TEXTS + [c["text"] for c in chunks]
+    emb = Embedder.from_local(d, device=gpu_device)
+    got = emb.encode(texts)
+    assert got.shape == (len(texts), 384) and got.dtype == np.float32
+    # the library stack on the host, fp32
+    tok = transformers.BertTokenizer(os.path.join(d, "vocab.txt"), do_lower_case=True)
+    enc = tok(texts, padding=True, truncation=True, max_length=256, return_tensors="pt")
+    with torch.no_grad():
+        hid = model(input_ids=enc["input_ids"], attention_mask=enc["attention_mask"]).last_hidden_state
+    m = enc["attention_mask"].unsqueeze(-1).float()
+    pooled = (hid * m).sum(1) / torch.clamp(m.sum(1), min=1e-9)
+    want = torch.nn.functional.normalize(pooled, p=2, dim=1).numpy()
+    # token ids agree exactly (native tokenizer vs the library's)
+    ids, lens = emb.tokenizer.batch_native(texts, 256)
+    for i in range(len(texts)):
+        assert ids[i, :lens[i]].tolist() == enc["input_ids"][i][:int(enc["attention_mask"][i].sum())].tolist()
+    cos = (got * want).sum(1)
+    assert cos.min() > 0.999, cos.min()
+    assert np.abs(got - want).max() < 1e-2, np.abs(got - want).max()    # fp16 weights / activations
+    # and the single-string form of SentenceTransformer.encode
+    one = emb.encode(texts[0])
+    assert one.shape == (384,) and np.abs(one - got[0]).max() < 2e-3

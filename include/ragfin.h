@@ -203,6 +203,10 @@ typedef struct rf_tokenizer rf_tokenizer_t;
 int rf_tokenizer_create(rf_tokenizer_t** out, const char* vocab_utf8, size_t vocab_bytes,
                         int do_lower_case, int max_chars_per_word);
 int rf_tokenizer_destroy(rf_tokenizer_t* t);
+/* Non-ASCII code points to split off as punctuation (Unicode category P*), so that text whose
+ * non-ASCII characters are all "simple" (caseless, no decomposition, not a mark / space /
+ * control / CJK ideograph) needs no pre-normalisation.  cps: int32 [n], any order. */
+int rf_tokenizer_set_punctuation(rf_tokenizer_t* t, const int32_t* cps, int n);
 /* ids5 <- { [UNK], [CLS], [SEP], [PAD], [MASK] (-1 if absent) } */
 int rf_tokenizer_special_ids(const rf_tokenizer_t* t, int32_t* ids5);
 /* text_bytes: the n texts' UTF-8 bytes back to back, text i = [offsets[i], offsets[i+1]).

@@ -34,6 +34,7 @@ struct rf_tokenizer {
   int32_t unk = -1, cls = -1, sep = -1, pad = -1, mask = -1;
   bool lower = true;
   int max_chars = 100;
+  std::vector<int32_t> punct;   // sorted non-ASCII code points to split off like ASCII punctuation
 };
 
 static inline bool ascii_punct(unsigned char c) {
@@ -94,6 +95,16 @@ extern "C" int rf_tokenizer_create(rf_tokenizer_t** out, const char* vocab_utf8,
 
 extern "C" int rf_tokenizer_destroy(rf_tokenizer_t* t) {
   delete t;
+  return RF_OK;
+}
+
+extern "C" int rf_tokenizer_set_punctuation(rf_tokenizer_t* t, const int32_t* cps, int n) {
+  if (!t || n < 0 || (n > 0 && !cps)) {
+    rf_set_error("rf_tokenizer_set_punctuation: bad argument");
+    return RF_ERR_INVALID;
+  }
+  t->punct.assign(cps, cps + n);
+  std::sort(t->punct.begin(), t->punct.end());
   return RF_OK;
 }
 
@@ -186,14 +197,28 @@ int encode_one(const rf_tokenizer& t, const char* s, size_t n, int max_len, int3
     const char* w = sc.word.data();
     const size_t wn = sc.word.size();
     size_t a = 0;
+    // punctuation = the four ASCII ranges, plus the non-ASCII code points the caller registered
+    // (rf_tokenizer_set_punctuation); returns the byte length of the punctuation character at p, or 0
+    auto punct_len = [&](size_t p) -> size_t {
+      const unsigned char c0 = (unsigned char)w[p];
+      if (c0 < 0x80) return ascii_punct(c0) ? 1 : 0;
+      if (t.punct.empty()) return 0;
+      const int len = utf8_len(c0);
+      if (p + (size_t)len > wn) return 0;
+      int32_t cp = len == 2 ? (c0 & 0x1f) : len == 3 ? (c0 & 0x0f) : (c0 & 0x07);
+      for (int q = 1; q < len; ++q) cp = (cp << 6) | ((unsigned char)w[p + q] & 0x3f);
+      return std::binary_search(t.punct.begin(), t.punct.end(), cp) ? (size_t)len : 0;
+    };
     while (a < wn && sc.ids.size() < limit) {
-      if (ascii_punct((unsigned char)w[a])) {
-        wordpiece(t, w + a, 1, sc);
-        ++a;
+      const size_t pl = punct_len(a);
+      if (pl) {
+        wordpiece(t, w + a, pl, sc);
+        a += pl;
         continue;
       }
       size_t b = a;
-      while (b < wn && !ascii_punct((unsigned char)w[b])) ++b;
+      while (b < wn && !punct_len(b)) b += (size_t)utf8_len((unsigned char)w[b]);
+      if (b > wn) b = wn;
       wordpiece(t, w + a, b - a, sc);
       a = b;
     }

@@ -58,9 +58,47 @@ def _clean_map(cp: int):
         return None
     if _is_cjk(cp):
         return " " + ch + " "
-    if _is_whitespace(ch):
+    if _is_whitespace(ch) or ch.isspace():   # Zl / Zp are not "whitespace" to _clean, but str.split() splits on them
         return " "
     return cp
+
+
+_SIMPLE = None
+
+
+def _simple_tables():
+    """(regex that finds a character needing the Python pre-pass, sorted list of 'simple'
+    non-ASCII punctuation code points).  A non-ASCII character is SIMPLE when the basic
+    tokenizer leaves it as it is: not a control / format / unassigned character, space or mark,
+    not a CJK ideograph or conjoining Hangul jamo, caseless, without a decomposition and with
+    combining class 0 -- so clean, NFC, lower, NFD and the Mn strip are all identities on text
+    made of ASCII and simple characters, and only punctuation splitting is left (done natively)."""
+    global _SIMPLE
+    if _SIMPLE is None:
+        import re
+        ranges, punct = [], []
+        start = prev = None
+        for cp in range(128, 0x110000):
+            ch = chr(cp)
+            cat = unicodedata.category(ch)
+            ok = (cp != 0xFFFD and cat[0] not in "CZM" and not _is_cjk(cp) and not unicodedata.combining(ch)
+                  and not unicodedata.decomposition(ch) and ch.lower() == ch
+                  and not (0x1100 <= cp <= 0x11FF or 0xA960 <= cp <= 0xA97F or 0xD7B0 <= cp <= 0xD7FF))
+            if ok:
+                if cat[0] == "P":
+                    punct.append(cp)
+                if prev is not None and cp == prev + 1:
+                    prev = cp
+                else:
+                    if start is not None:
+                        ranges.append((start, prev))
+                    start = prev = cp
+        if start is not None:
+            ranges.append((start, prev))
+        cls = "".join(re.escape(chr(a)) if a == b else re.escape(chr(a)) + "-" + re.escape(chr(b))
+                      for a, b in ranges)
+        _SIMPLE = (re.compile("[^\\x00-\\x7f" + cls + "]"), punct)
+    return _SIMPLE
 
 
 class WordPieceTokenizer:
@@ -174,6 +212,11 @@ class WordPieceTokenizer:
             h = c_void_p()
             _lib.check(lib.rf_tokenizer_create(byref(h), blob, len(blob), 1 if self.do_lower_case else 0,
                                                self.max_chars))
+            complex_re, punct = _simple_tables()
+            import numpy as np
+            arr = np.asarray(punct, dtype=np.int32)
+            _lib.check(lib.rf_tokenizer_set_punctuation(h, c_void_p(arr.ctypes.data), len(punct)))
+            self._complex_re = complex_re
             self._nat = (lib, h)
             self._clean_tab = _LazyTable(_clean_map)
             self._mn_tab = _LazyTable(lambda cp: None if unicodedata.category(chr(cp)) == "Mn" else cp)
@@ -211,7 +254,7 @@ class WordPieceTokenizer:
             return np.full((0, 1), self.pad_id, dtype=np.int32), np.zeros((0,), dtype=np.int32)
         enc, python_rows = [], {}
         for i, t in enumerate(texts):
-            if not t.isascii():
+            if not t.isascii() and self._complex_re.search(t) is not None:
                 t = self._prenormalise(t)
                 if t is None:
                     python_rows[i] = self.encode(texts[i], max_length)

@@ -31,7 +31,7 @@ def _texts():
     texts = [c["text"] for c in chunks]
     rng = random.Random(0)
     alphabet = ("abcdefghij KLMNOP.,;:!?()[]{}-_/\\'\"0123456789 \t\n₹•é中ßİ́"
-                "​�\U0001f600")
+                "​�\U0001f600«»—…€№√א٣अািか한가ǅΣς\u2028\u00a0\u00ad")
     fuzz = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 300))) for _ in range(1500)]
     return texts, texts + EDGE + fuzz
 

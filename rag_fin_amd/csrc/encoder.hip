@@ -499,8 +499,6 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int t0 = blockIdx.x * LD_TOK;
-  const int M = *m_ptr;
-  if (t0 >= M) return;   // whole workgroup
   const int tb = wave & 3, par = wave >> 2;
   const uint32_t n_ph = (uint32_t)N / 64u;
   const uint32_t nblk = (uint32_t)N / 32u;
@@ -529,6 +527,16 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pc.src + j * pc.sstep),
                                      (__attribute__((address_space(3))) void*)(pc.dst + j * pc.dstep), 16, 0, 0);
   };
+  // Prologue order = dependency order: the activations (needed by the first MFMA), then the first
+  // two phases of the weight stream, and only then the token count -- every read above is legal
+  // for any workgroup of the grid (buffers are padded to whole tiles), so the early exit of the
+  // workgroups past the packed token count does not have to sit in front of them.
+  rf_u32x4 xf[KS];   // this wave's 32 tokens as B-operand fragments (fragment (token block, kk) = 1 KiB)
+  {
+    const _Float16* xfrag = X + (((size_t)(t0 >> 5) + tb) * KS * 64 + lane) * 8;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) xf[kk] = *(const rf_u32x4*)(xfrag + (size_t)kk * 512);
+  }
   {
     const Pieces p0 = pieces_of(0), p1 = pieces_of(1);
 #pragma unroll
@@ -536,12 +544,10 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
 #pragma unroll
     for (int j = 0; j < LD_PW; ++j) issue_piece(p1, j);
   }
-  // this wave's 32 tokens as B-operand fragments (fragment (token block, kk) = 1 KiB contiguous)
-  rf_u32x4 xf[KS];
-  {
-    const _Float16* xfrag = X + (((size_t)(t0 >> 5) + tb) * KS * 64 + lane) * 8;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) xf[kk] = *(const rf_u32x4*)(xfrag + (size_t)kk * 512);
+  const int M = *m_ptr;
+  if (t0 >= M) {   // whole workgroup; its LDS-DMA pieces must land before the LDS is handed on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
   }
   for (int i = tid; i < N / 8; i += LD_WAVES * 64) *(uint4*)(bias_l + i * 8) = *(const uint4*)(bias + i * 8);
 #pragma unroll

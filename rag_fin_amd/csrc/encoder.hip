@@ -1055,6 +1055,10 @@ extern "C" int rf_debug_set_buffer(void* dev_ptr) {
 }
 int rf_debug_linear_flags = 0;   // ablation bits of k_linear_dma (rf_set_tuning("linear_dbg", v))
 int rf_debug_epi = 1;   // which k_linear_dma epilogue (0 QKV, 1 FFN1) writes the stamps
+int rf_tuning_ffn2_ntb = 4;   // token blocks per workgroup of the K = 1536 LayerNorm GEMM (2 | 4): 128-token tiles
+                              // halve the weight traffic per token (22.4 vs 21.7 M tokens/s)
+int rf_tuning_k384_ntb = 4;   // the same for the K = 384 direct-load GEMM that is left at large batch (out-proj + LN: +1 %;
+                              // for QKV / FFN1 with linear_dma = 0 the 64-token tiles are faster: 21.1 vs 19.8 M tokens/s)
 int rf_tuning_linear_small = 1;   // B * T <= SM_MAX_TOK: feature-split GEMMs + separate LayerNorm (A/B knob)
 int rf_tuning_linear_dma = 1;   // K = 384 GEMMs with plain epilogues through the LDS-DMA ring (A/B knob)
 
@@ -1091,9 +1095,15 @@ static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Floa
                        N, m_ptr, (rf_debug_epi == (int)EPI) ? (float*)rf_debug_buffer : nullptr, rf_debug_linear_flags);
     return;
   }
-  if (K == 384)
+  if (K == 384 && rf_tuning_k384_ntb == 4 && tokens >= 8192)   // 128-token tiles
+    hipLaunchKernelGGL((k_linear<EPI, 4, 24>), dim3((tokens + 127) / 128, N / 384), dim3(256), 0, st, X, K, Wt, bias,
+                       out, N, m_ptr, res, g, b, eps);
+  else if (K == 384)
     hipLaunchKernelGGL((k_linear<EPI, NTB, 24>), dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out,
                        N, m_ptr, res, g, b, eps);
+  else if (rf_tuning_ffn2_ntb == 4 && tokens >= 8192)   // experiment: 128-token tiles for the K = 1536 GEMM
+    hipLaunchKernelGGL((k_linear<EPI, 4, 96>), dim3((tokens + 127) / 128, N / 384), dim3(256), 0, st, X, K, Wt, bias,
+                       out, N, m_ptr, res, g, b, eps);
   else   // K == 1536 (checked by rf_encoder_create: intermediate == 4 * hidden is the only other K)
     hipLaunchKernelGGL((k_linear<EPI, NTB, 96>), dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out,
                        N, m_ptr, res, g, b, eps);

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batch-tokens", type=int, default=32768)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--fixed-len", type=int, default=0)
+    ap.add_argument("--tune", default="", help="rf_set_tuning pairs, e.g. ffn2_ntb=4,linear_dma=0")
     ap.add_argument("--texts", action="store_true", help="also time the text -> tokenizer -> encoder path")
     ap.add_argument("--stamps", action="store_true", help="clock stamps of the last k_linear_dma launch")
     ap.add_argument("--stamp-epi", type=int, default=1, help="0 = QKV, 1 = FFN1")
@@ -33,6 +34,11 @@ def main():
     dev = torch.device("cuda:0")
     cfg = dict(oenc.MINILM_L6)
     emb = Embedder(oenc.random_weights(cfg, 0), cfg, device=dev)
+    if args.tune:
+        from rag_fin_amd import _lib
+        for kv in args.tune.split(","):
+            k_, v_ = kv.split("=")
+            _lib.check(_lib.load_library().rf_set_tuning(k_.encode(), int(v_)))
     rng = np.random.default_rng(7)
     lens = (np.full(args.chunks, args.fixed_len) if args.fixed_len
             else rng.integers(40, 251, args.chunks)).astype(np.int32)

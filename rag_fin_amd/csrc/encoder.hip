@@ -148,7 +148,7 @@ static size_t enc_carve(unsigned char* base, int B, int T, int I, EncWs* ws) {
     off = (off + bytes + 255) / 256 * 256;
     return p;
   };
-  const size_t Mpad = ((size_t)B * T + 127) / 128 * 128;   // k_linear_dma reads whole 128-token tiles
+  const size_t Mpad = ((size_t)B * T + 255) / 256 * 256;   // k_linear_dma reads whole 128- / 256-token tiles
   int32_t* tok = (int32_t*)take(((size_t)B + 1) * 4);
   _Float16* x = (_Float16*)take(Mpad * HID * 2);
   _Float16* y = (_Float16*)take(Mpad * HID * 2);
@@ -481,7 +481,11 @@ __global__ void __launch_bounds__(256) k_linear(
 #define LD_SLOTS 3
 #define LD_FRAGS 48                       // fragments per phase: 2 feature blocks x 24 k-steps
 #define LD_PW (LD_FRAGS / LD_WAVES)       // LDS-DMA pieces per wave and phase (6)
-template <int EPI>
+// WIDE = 0: 128 tokens per workgroup, waves w / w + 4 share a token block and split each phase's
+// two feature blocks; WIDE = 1: 256 tokens per workgroup, every wave owns a token block and takes
+// BOTH feature blocks of a phase (the per-wave fixed costs -- six LDS-DMA issues, a barrier --
+// are paid once per 48 MFMAs instead of once per 24, and a weight byte serves 256 tokens).
+template <int EPI, int WIDE>
 __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
     const _Float16* __restrict__ X, const uint4* __restrict__ Wt, const _Float16* __restrict__ bias,
     _Float16* __restrict__ out, int N, const int32_t* __restrict__ m_ptr, float* __restrict__ dbg, int dbg_flags) {
@@ -498,8 +502,8 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
-  const int t0 = blockIdx.x * LD_TOK;
-  const int tb = wave & 3, par = wave >> 2;
+  const int t0 = blockIdx.x * (WIDE ? 2 * LD_TOK : LD_TOK);
+  const int tb = WIDE ? wave : (wave & 3);
   const uint32_t n_ph = (uint32_t)N / 64u;
   const uint32_t nblk = (uint32_t)N / 32u;
 
@@ -563,7 +567,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
   const uint32_t bias_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)bias_l + (uint32_t)h * 8u;
   f32x16 acc;
   // matrix part of a phase: this wave's feature block (par) of the slot x its 32 tokens
-  auto mfma_part = [&](uint32_t ph, const Pieces& nxt) {
+  auto mfma_part = [&](uint32_t ph, const Pieces& nxt, int par, bool with_dma) {
     const rf_u32x4* slot = slots + ((ph % LD_SLOTS) * LD_FRAGS + par * KS) * 64 + lane;
     const uint32_t sa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)slot;
     rf_u32x4 fa[2][WL_GRP];
@@ -577,7 +581,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
       } else {
         lds_wait_group<0>(fa[g & 1]);
       }
-      if (g < LD_PW && !(dbg_flags & 2)) issue_piece(nxt, g);   // one LDS-DMA piece per group of 4 MFMAs
+      if (with_dma && g < LD_PW && !(dbg_flags & 2)) issue_piece(nxt, g);   // one LDS-DMA piece per group of 4 MFMAs
 #pragma unroll
       for (int j = 0; j < WL_GRP; ++j) {
         const int kk = g * WL_GRP + j;
@@ -629,8 +633,9 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
     uint64_t ts0 = 0;
     if (dbg) ts0 = __builtin_amdgcn_s_memtime();
     // the previous phase issued, after the barrier that follows my pieces of phase ph, exactly 6
-    // pieces (phase ph+1) and 4 stores: those 10 may stay in flight, everything older has landed
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + 4) : "memory");
+    // pieces (phase ph+1) and 4 stores (8 in the WIDE form): those may stay in flight, everything
+    // older has landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + (WIDE ? 8 : 4)) : "memory");
     __builtin_amdgcn_s_barrier();
     if (dbg) t_wait += __builtin_amdgcn_s_memtime() - ts0;
     const Pieces nxt = pieces_of(ph + 2);
@@ -638,8 +643,16 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
     // OPPOSITE orders (one's MFMAs over the other's epilogue and DMA issues, pieces issued in a
     // burst): 5 300 cycles per phase instead of 4 300 -- a burst of six LDS-DMA issues costs more
     // than six issues spread over the MFMA groups.
-    mfma_part(ph, nxt);
-    if (!(dbg_flags & 4)) epilogue(2u * ph + (uint32_t)par);
+    if (WIDE) {
+      mfma_part(ph, nxt, 0, true);
+      if (!(dbg_flags & 4)) epilogue(2u * ph);
+      mfma_part(ph, nxt, 1, false);
+      if (!(dbg_flags & 4)) epilogue(2u * ph + 1u);
+    } else {
+      const int par = wave >> 2;
+      mfma_part(ph, nxt, par, true);
+      if (!(dbg_flags & 4)) epilogue(2u * ph + (uint32_t)par);
+    }
   }
   if (dbg_flags & 4) asm volatile("" : "+a"(acc));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump pieces must land before the LDS is handed on
@@ -1085,14 +1098,23 @@ static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Floa
   }
   if (K == 384 && EPI != EPI_BIAS_RES_LN && rf_tuning_linear_dma && tokens >= 8192) {
     const size_t lds = (size_t)LD_SLOTS * LD_FRAGS * RF_FRAG_BYTES + RF_FRAG_BYTES + (size_t)N * 2;
-    auto kern = k_linear_dma<(EPI == EPI_BIAS_GELU ? EPI_BIAS_GELU : EPI_BIAS)>;
-    static size_t attr = 0;
-    if (lds > attr) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = lds;
+    constexpr int E = (EPI == EPI_BIAS_GELU ? EPI_BIAS_GELU : EPI_BIAS);
+    // 256-token workgroups once they still fill the chip (>= 256 of them would need 64 k tokens;
+    // from ~48 k the halved weight traffic and per-wave overhead outweigh the idle CUs)
+    const bool wide = rf_tuning_linear_dma == 2 || (rf_tuning_linear_dma == 1 && tokens >= 49152);   // 3: never
+    static size_t attr[2] = {0, 0};
+    if (lds > attr[wide]) {
+      if (wide) (void)hipFuncSetAttribute((const void*)k_linear_dma<E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      else (void)hipFuncSetAttribute((const void*)k_linear_dma<E, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr[wide] = lds;
     }
-    hipLaunchKernelGGL(kern, dim3((tokens + LD_TOK - 1) / LD_TOK), dim3(LD_WAVES * 64), lds, st, X, Wt, bias, out,
-                       N, m_ptr, (rf_debug_epi == (int)EPI) ? (float*)rf_debug_buffer : nullptr, rf_debug_linear_flags);
+    float* dbgp = (rf_debug_epi == (int)EPI) ? (float*)rf_debug_buffer : nullptr;
+    if (wide)
+      hipLaunchKernelGGL((k_linear_dma<E, 1>), dim3((tokens + 2 * LD_TOK - 1) / (2 * LD_TOK)), dim3(LD_WAVES * 64), lds,
+                         st, X, Wt, bias, out, N, m_ptr, dbgp, rf_debug_linear_flags);
+    else
+      hipLaunchKernelGGL((k_linear_dma<E, 0>), dim3((tokens + LD_TOK - 1) / LD_TOK), dim3(LD_WAVES * 64), lds, st, X,
+                         Wt, bias, out, N, m_ptr, dbgp, rf_debug_linear_flags);
     return;
   }
   if (K == 384 && rf_tuning_k384_ntb == 4 && tokens >= 8192)   // 128-token tiles

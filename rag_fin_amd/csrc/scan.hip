@@ -346,7 +346,7 @@ extern "C" int rf_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "emit_wgs_per_cu") && value >= 0 && value <= 4) t.emit_wgs_per_cu = value;
   else if (!strcmp(key, "sample_bpw") && value >= 1 && value <= 8) t.sample_bpw = value;
   else if (!strcmp(key, "qreg") && (value == 0 || value == 1)) t.qreg = value;
-  else if (!strcmp(key, "linear_dma") && (value == 0 || value == 1)) rf_tuning_linear_dma = value;
+  else if (!strcmp(key, "linear_dma") && value >= 0 && value <= 3) rf_tuning_linear_dma = value;
   else if (!strcmp(key, "k384_ntb") && (value == 2 || value == 4)) rf_tuning_k384_ntb = value;
   else if (!strcmp(key, "ffn2_ntb") && (value == 2 || value == 4)) rf_tuning_ffn2_ntb = value;
   else if (!strcmp(key, "linear_small") && (value == 0 || value == 1)) rf_tuning_linear_small = value;

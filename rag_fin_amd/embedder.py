@@ -181,7 +181,7 @@ class Embedder:
                                           _lib.current_stream_ptr()))
         return out32 if want32 else out16
 
-    def encode_to_device(self, sentences, batch_tokens: int = 16384):
+    def encode_to_device(self, sentences, batch_tokens: int = 65536):
         """Tokenise, bucket by length, encode; returns fp16 [n, 384] on the device in
         the input order."""
         torch = _torch()

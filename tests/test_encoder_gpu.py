@@ -139,7 +139,9 @@ def test_all_gemm_paths_agree_and_match_the_oracle(gpu_device):
     ids = rng.integers(1, 3000, (B, T)).astype(np.int32)
     dma = enc(ids, lens)
     direct = enc(ids, lens, linear_dma=0)
+    dma_wide = enc(ids, lens, linear_dma=2)          # 256-token workgroups (default from 49 152 slots)
     assert np.abs(dma - direct).max() < 2e-3
+    assert np.array_equal(dma, dma_wide)             # same arithmetic per (token, feature): bit-identical
     sub = [0, 1, 7, 39]
     want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids[sub], lens[sub])
     assert np.abs(dma[sub] - want).max() < TOL and np.abs(direct[sub] - want).max() < TOL

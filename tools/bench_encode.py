@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chunks", type=int, default=10_000)
-    ap.add_argument("--batch-tokens", type=int, default=32768)
+    ap.add_argument("--batch-tokens", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--fixed-len", type=int, default=0)
     ap.add_argument("--tune", default="", help="rf_set_tuning pairs, e.g. ffn2_ntb=4,linear_dma=0")

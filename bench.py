@@ -9,14 +9,16 @@ the HBM-resident corpus -> ranked (score, row id) lists in HBM.
   python bench.py --gpus 1 --steps 50 --warmup 5
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: the corpus is row-sharded (1M rows per GPU, weak scaling), the query batch
-is replicated, and each step ends with ONE RCCL all-gather of the per-shard top-k
-plus a merge (rag_fin_amd/sharded.py); batches in flight work the same way (the
-all-gathers of the lanes share one communicator and are issued in the same order
-on every rank).  `value` stays "queries/sec of the whole
-job" -- the job answers the same 64 queries per step against an N-times larger
-corpus -- so under weak scaling the ideal is a flat value; `rows_per_s` in the
-JSON carries the aggregate scan rate that grows with N.
+N > 1: the corpus is row-sharded, the query batch is replicated, and each step ends
+with ONE RCCL all-gather of the per-shard top-k plus a merge (rag_fin_amd/sharded.py);
+batches in flight work the same way (the all-gathers of the lanes share one
+communicator and are issued in the same order on every rank).
+Default = STRONG scaling: the metric's 1M-row corpus is split over the N GPUs (rank r
+holds rows [r N/W, (r+1) N/W)), so `value` -- queries/sec of the whole job -- grows
+with N until the per-step latency floor (three enqueues + collective, ~50 us) is
+reached; at 8 GPUs a shard is 125k rows = 15 us of scan.  `--scaling weak` keeps
+--rows rows PER GPU instead (capacity scaling, BASELINE configs[4] style: the same 64
+queries against an N-times larger corpus; ideal = flat value, `rows_per_s` grows).
 """
 from __future__ import annotations
 
@@ -39,7 +41,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=1_000_000, help="corpus rows PER GPU")
+    ap.add_argument("--rows", type=int, default=1_000_000,
+                    help="corpus rows of the whole job (--scaling strong) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--topk", type=int, default=10)
@@ -67,6 +71,11 @@ def pmc_traffic(rows, dim, batch):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON: everything any library prints to fd 1 before that (RCCL's
+    # version banner, for one) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -105,8 +114,13 @@ def main():
     from rag_fin_amd.sharded import HipShardBackend, ShardedSearcher
     from rag_fin_amd.store import GpuIndex
 
-    rows, dim, B, k = args.rows, args.dim, args.batch, args.topk
-    # synthetic data, SURVEY.md 8d recipe: N(0,1) rows, L2-normalised, fp16
+    dim, B, k = args.dim, args.batch, args.topk
+    if args.scaling == "strong" and world > 1:
+        lo, hi = ShardedSearcher.shard_bounds(args.rows, world, rank)
+        rows, row_base, rows_total = hi - lo, lo, args.rows
+    else:
+        rows, row_base, rows_total = args.rows, rank * args.rows, args.rows * world
+    # synthetic data, SURVEY.md 8d recipe: N(0,1) rows, L2-normalised, fp16 (each rank its own shard)
     c16 = osearch.synth_unit_rows(rows, dim, 1234 + rank)
     q16 = osearch.synth_unit_rows(B, dim, 5678)
     index = GpuIndex(dim, rows, dev)
@@ -116,7 +130,7 @@ def main():
     q = torch.from_numpy(q16).to(dev)
     torch.cuda.synchronize()
 
-    searcher = ShardedSearcher(HipShardBackend(index), row_base=rank * rows) if (world > 1 or force_sharded) else None
+    searcher = ShardedSearcher(HipShardBackend(index), row_base=row_base) if (world > 1 or force_sharded) else None
     if force_sharded:
         searcher.force_collective = True
     # `streams` batches in flight: each has its own HIP stream, workspace and output
@@ -197,19 +211,19 @@ def main():
         traffic = pmc_traffic(rows, dim, B)
         result = {
             "metric": "queries/sec, brute-force cosine/IP top-%d over a %s x %d-d fp16 corpus, "
-                      "batch=%d (recall@10 vs CPU oracle reported alongside)" % (k, f"{rows:,}", dim, B),
+                      "batch=%d (recall@10 vs CPU oracle reported alongside)" % (k, f"{rows_total:,}", dim, B),
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": "1M x 384-d fp16 corpus, batch-64 queries, top-10"
-                       if (rows, dim, B, k) == (1_000_000, 384, 64, 10)
-                       else f"{rows} x {dim}-d fp16 corpus per GPU, batch-{B}, top-{k}",
-                       "rows_per_gpu": rows, "rows_total": rows * world, "dim": dim, "batch": B,
+                       if (rows_total, dim, B, k) == (1_000_000, 384, 64, 10)
+                       else f"{rows_total} x {dim}-d fp16 corpus ({rows} rows per GPU), batch-{B}, top-{k}",
+                       "rows_per_gpu": rows, "rows_total": rows_total, "dim": dim, "batch": B,
                        "topk": k, "batches_in_flight": n_lanes,
                        "sharding": ("none" if not force_sharded else "one-rank RCCL all-gather (overhead rehearsal)")
                        if world == 1 else f"rows/{world} + RCCL all-gather"},
-            "rows_per_s": round(rows * world * args.steps / elapsed, 1),
+            "rows_per_s": round(rows_total * args.steps / elapsed, 1),
             "serial": {"batches_in_flight": 1, "value": round(B * args.steps / serial_s, 1),
                        "ms_per_step": round(serial_s * 1e3 / args.steps, 5),
                        "whole_step_GBps": round(alg_bytes / (serial_s / args.steps) / 1e9, 1)},
@@ -293,7 +307,10 @@ def main():
                 "sample": f"{len(times)} full batches of the same workload ({rows} x {dim}, batch {B}, "
                           f"top-{k}); numpy float32 BLAS matmul + argpartition (oracle/search.py "
                           f"cpu_search_blas), median {med * 1e3:.1f} ms/batch"}
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
         print(json.dumps(result), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.barrier()
     if world > 1 or force_sharded:

@@ -376,7 +376,10 @@ static int dispatch_scan(int KS, int JB, const ScanParams& p, int grid4, int gri
   // HBM is saturated), the short sample pass with the full-block ring (16 vs 21 us:
   // it has two blocks per wave and must prefetch the second during the first).
   if (KS == 24 && MODE == MODE_EMIT) {
-    switch (tuning().ring24) {
+    // short sweeps (a few blocks per wave: shards of a strong-scaled job, BASELINE configs[1]) are
+    // latency-bound like the sample pass and prefer the full-block ring too: 21.7 vs 23.3 us at 100 k rows
+    const int ring = (p.n_work < 6u * 4u * (uint32_t)grid4) ? 24 : tuning().ring24;
+    switch (ring) {
       case 6:
         return JB == 1 ? launch_scan<24, 6, 1, 4, MODE>(p, grid4, st) : launch_scan<24, 6, 2, 4, MODE>(p, grid4, st);
       case 8:

@@ -51,6 +51,10 @@ def parse():
                     help="batches in flight (one HIP stream + workspace each); 1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--group", action="store_true",
+                    help="N > 1: one all-gather per group of batches in flight (ShardedSearcher.search_group) instead "
+                         "of one per batch -- measured SLOWER in the one-GPU rehearsal (58 vs 50 us/step at 125 k-row "
+                         "shards: the groups serialise on the shared buffers), kept as an experiment")
     ap.add_argument("--no-batch256", action="store_true", help="skip the configs[2] (batch 256) side measurement")
     return ap.parse_args()
 
@@ -166,12 +170,28 @@ def main():
                     res[0] = lane["res"]
                 else:
                     index.search_raw(q, k, want_exact=True, out=lane["out"], workspace=lane["ws"])
-        for _ in range(args.warmup):
-            step()
+
+        # --group (experiment): the lanes' per-shard top-k share ONE all-gather
+        # (ShardedSearcher.search_group); `n` steps = n // lanes groups + a remainder of single steps
+        grouped = searcher is not None and n_lanes > 1 and args.group
+        side = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if grouped else None
+
+        def run(n):
+            if not grouped:
+                for _ in range(n):
+                    step()
+                return
+            for _ in range(n // n_lanes):
+                g = searcher.search_group([q] * n_lanes, k, [l["ws"] for l in lanes[:n_lanes]], side)
+                res[0] = (g[0][-1], g[1][-1], g[2][-1])
+                for i in range(n_lanes):
+                    lanes[i]["res"] = (g[0][i], g[1][i], g[2][i])
+            for _ in range(n % n_lanes):
+                step()
+        run(args.warmup)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        run(args.steps)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -221,6 +241,9 @@ def main():
                        else f"{rows_total} x {dim}-d fp16 corpus ({rows} rows per GPU), batch-{B}, top-{k}",
                        "rows_per_gpu": rows, "rows_total": rows_total, "dim": dim, "batch": B,
                        "topk": k, "batches_in_flight": n_lanes,
+                       "collective": ("none" if searcher is None else
+                                      ("one all-gather per %d batches" % n_lanes if (n_lanes > 1 and args.group)
+                                       else "one all-gather per batch")),
                        "sharding": ("none" if not force_sharded else "one-rank RCCL all-gather (overhead rehearsal)")
                        if world == 1 else f"rows/{world} + RCCL all-gather"},
             "rows_per_s": round(rows_total * args.steps / elapsed, 1),

@@ -129,6 +129,12 @@ int rf_merge_shards(const double* exact_dev, const int64_t* ids_dev, int W, int 
  * no repacking kernel runs between the scan, the collective and the merge. */
 int rf_merge_shards_packed(const int64_t* packed_dev, int W, int B, int k,
                            float* scores_out_dev, int64_t* ids_out_dev, void* stream);
+/* The same for L batches in flight whose per-shard results travelled in ONE all-gather:
+ * packed_dev int64 [W][L][2][B][k] -> scores [L][B][k], ids [L][B][k], one launch.  (The
+ * collective costs ~30 us of host time per call: with 125 k-row shards it, not the scan, sets
+ * the step time, so the lanes share it.) */
+int rf_merge_shards_group(const int64_t* packed_dev, int W, int L, int B, int k,
+                          float* scores_out_dev, int64_t* ids_out_dev, void* stream);
 /* Tuning hook (experiments / A-B runs in one process): key in {"ring24",
  * "emit_wgs_per_cu", "sample_bpw"}.  No reference counterpart. */
 int rf_set_tuning(const char* key, int value);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "rf_merge_shards": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p]),
     "rf_merge_shards_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rf_merge_shards_group": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rf_tokenizer_create": (c_int, [POINTER(c_void_p), c_char_p, c_size_t, c_int, c_int]),
     "rf_tokenizer_destroy": (c_int, [c_void_p]),
     "rf_tokenizer_set_punctuation": (c_int, [c_void_p, c_void_p, c_int]),

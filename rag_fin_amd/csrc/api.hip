@@ -291,7 +291,7 @@ extern "C" int rf_merge_shards(const double* exact_dev, const int64_t* ids_dev, 
     rf_set_error("rf_merge_shards: bad argument");
     return RF_ERR_INVALID;
   }
-  return rf_launch_merge_shards(exact_dev, ids_dev, (size_t)B * k, W, B, k, scores_out_dev, ids_out_dev,
+  return rf_launch_merge_shards(exact_dev, ids_dev, (size_t)B * k, 0, W, 1, B, k, scores_out_dev, ids_out_dev,
                                 (hipStream_t)stream);
 }
 
@@ -302,8 +302,19 @@ extern "C" int rf_merge_shards_packed(const int64_t* packed_dev, int W, int B, i
     return RF_ERR_INVALID;
   }
   // shard w = { fp64 score bits [B, k], int64 ids [B, k] }: 2 B k words per shard
-  return rf_launch_merge_shards((const double*)packed_dev, packed_dev + (size_t)B * k, (size_t)2 * B * k, W,
+  return rf_launch_merge_shards((const double*)packed_dev, packed_dev + (size_t)B * k, (size_t)2 * B * k, 0, W, 1,
                                 B, k, scores_out_dev, ids_out_dev, (hipStream_t)stream);
+}
+
+extern "C" int rf_merge_shards_group(const int64_t* packed_dev, int W, int L, int B, int k,
+                                     float* scores_out_dev, int64_t* ids_out_dev, void* stream) {
+  if (!packed_dev || !scores_out_dev || !ids_out_dev || W <= 0 || L <= 0 || B <= 0 || k <= 0) {
+    rf_set_error("rf_merge_shards_group: bad argument");
+    return RF_ERR_INVALID;
+  }
+  // packed [W][L][2][B][k]: L batches ("lanes") gathered by ONE collective, merged by one launch
+  return rf_launch_merge_shards((const double*)packed_dev, packed_dev + (size_t)B * k, (size_t)L * 2 * B * k,
+                                (size_t)2 * B * k, W, L, B, k, scores_out_dev, ids_out_dev, (hipStream_t)stream);
 }
 
 extern "C" int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,

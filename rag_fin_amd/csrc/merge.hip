@@ -502,28 +502,30 @@ __global__ void __launch_bounds__(EX_THREADS) k_exhaustive_final(
 // in [W][B][k] (exact fp64, global id) -> out [B][k].  Ids are global and unique,
 // so ranking by (score desc, id asc) reproduces the single-device order bit for bit.
 __global__ void __launch_bounds__(EX_THREADS) k_merge_shards(
-    const double* __restrict__ in_s, const int64_t* __restrict__ in_r, size_t sstride, int W, int B,
-    int k, float* __restrict__ scores, int64_t* __restrict__ ids) {
-  // entry (shard w, query qi, rank j) sits at w * sstride + qi * k + j in both arrays
+    const double* __restrict__ in_s, const int64_t* __restrict__ in_r, size_t sstride, size_t lstride,
+    int W, int B, int k, float* __restrict__ scores, int64_t* __restrict__ ids) {
+  // entry (shard w, lane l = blockIdx.y, query qi, rank j) sits at w * sstride + l * lstride + qi * k + j
+  // in both arrays; outputs are [lane][B][k]
   const int qi = blockIdx.x;
   const int tid = threadIdx.x;
   const int m = W * k;
-  (void)B;
+  const size_t qoff = (size_t)blockIdx.y * lstride + (size_t)qi * k;
+  const size_t ooff = ((size_t)blockIdx.y * B + qi) * k;
   for (int i = tid; i < m; i += EX_THREADS) {
     const int w = i / k, j = i % k;
-    const size_t src = (size_t)w * sstride + (size_t)qi * k + j;
+    const size_t src = (size_t)w * sstride + qoff + j;
     const int64_t ri = in_r[src];
     if (ri < 0) continue;
     const double si = in_s[src];
     int rank = 0;
     for (int i2 = 0; i2 < m; ++i2) {
-      const size_t s2 = (size_t)(i2 / k) * sstride + (size_t)qi * k + (i2 % k);
+      const size_t s2 = (size_t)(i2 / k) * sstride + qoff + (i2 % k);
       const int64_t r2 = in_r[s2];
       if (r2 >= 0 && ranks_before(in_s[s2], r2, si, ri)) ++rank;
     }
     if (rank < k) {
-      scores[(size_t)qi * k + rank] = (float)si;
-      ids[(size_t)qi * k + rank] = ri;
+      scores[ooff + rank] = (float)si;
+      ids[ooff + rank] = ri;
     }
   }
   // number of valid entries decides how many tail slots stay empty
@@ -532,12 +534,12 @@ __global__ void __launch_bounds__(EX_THREADS) k_merge_shards(
   __syncthreads();
   int mine = 0;
   for (int i = tid; i < m; i += EX_THREADS)
-    mine += in_r[(size_t)(i / k) * sstride + (size_t)qi * k + (i % k)] >= 0 ? 1 : 0;
+    mine += in_r[(size_t)(i / k) * sstride + qoff + (i % k)] >= 0 ? 1 : 0;
   if (mine) atomicAdd(&n_valid, mine);
   __syncthreads();
   for (int j = n_valid + tid; j < k; j += EX_THREADS) {
-    scores[(size_t)qi * k + j] = -INFINITY;
-    ids[(size_t)qi * k + j] = -1;
+    scores[ooff + j] = -INFINITY;
+    ids[ooff + j] = -1;
   }
 }
 
@@ -583,10 +585,10 @@ int rf_launch_exhaustive(const rf_index* ix, const void* q, int B, int k, int64_
   return RF_OK;
 }
 
-int rf_launch_merge_shards(const double* exact, const int64_t* ids, size_t shard_stride, int W, int B,
-                           int k, float* scores_out, int64_t* ids_out, hipStream_t st) {
-  hipLaunchKernelGGL(k_merge_shards, dim3(B), dim3(EX_THREADS), 0, st, exact, ids, shard_stride, W, B, k,
-                     scores_out, ids_out);
+int rf_launch_merge_shards(const double* exact, const int64_t* ids, size_t shard_stride, size_t lane_stride,
+                           int W, int L, int B, int k, float* scores_out, int64_t* ids_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_merge_shards, dim3(B, L), dim3(EX_THREADS), 0, st, exact, ids, shard_stride, lane_stride, W,
+                     B, k, scores_out, ids_out);
   RF_HIP(hipGetLastError());
   return RF_OK;
 }

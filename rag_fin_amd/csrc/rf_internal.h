@@ -103,8 +103,8 @@ int rf_launch_merge(const rf_index* ix, const void* q, int B, int k, int64_t id_
 int rf_launch_exhaustive(const rf_index* ix, const void* q, int B, int k, int64_t id_base,
                          const rf_workspace& ws, float* scores, int64_t* ids, double* exact,
                          const double* after_s, const int64_t* after_r, hipStream_t st);
-int rf_launch_merge_shards(const double* exact, const int64_t* ids, size_t shard_stride, int W, int B,
-                           int k, float* scores_out, int64_t* ids_out, hipStream_t st);
+int rf_launch_merge_shards(const double* exact, const int64_t* ids, size_t shard_stride, size_t lane_stride,
+                           int W, int L, int B, int k, float* scores_out, int64_t* ids_out, hipStream_t st);
 
 // order-preserving map float -> uint32 (larger float <=> larger uint)
 __host__ __device__ inline uint32_t rf_f2ord(float f) {

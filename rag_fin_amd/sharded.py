@@ -70,6 +70,32 @@ class HipShardBackend:
         import torch
         return torch.cuda.device(self.device)
 
+    # -- several batches in flight sharing ONE collective -------------------------------------
+    def new_group(self, L: int, B: int, k: int, world: int):
+        import torch
+        dev = self.device
+        return dict(
+            L=L, B=B, k=k, world=world,
+            send=torch.empty((L, 2, B, k), dtype=torch.int64, device=dev),
+            recv=torch.empty((world, L, 2, B, k), dtype=torch.int64, device=dev),
+            local_scores=torch.empty((L, B, k), dtype=torch.float32, device=dev),
+            flags=torch.empty((L, B), dtype=torch.int32, device=dev),
+            scores=torch.empty((L, B, k), dtype=torch.float32, device=dev),
+            ids=torch.empty((L, B, k), dtype=torch.int64, device=dev))
+
+    def local_topk_group(self, q16, k: int, row_base: int, grp, lane: int, workspace):
+        send = grp["send"]
+        self.index.search_raw(q16, k, id_base=row_base, want_exact=True, workspace=workspace,
+                              out=(grp["local_scores"][lane], send[lane, 1], send[lane, 0].view(self._f64()),
+                                   grp["flags"][lane]))
+
+    def merge_group(self, recv, grp):
+        with self._device_ctx():
+            _lib.check(self.lib.rf_merge_shards_group(
+                c_void_p(recv.data_ptr()), grp["world"], grp["L"], grp["B"], grp["k"],
+                c_void_p(grp["scores"].data_ptr()), c_void_p(grp["ids"].data_ptr()), _lib.current_stream_ptr()))
+        return grp["scores"], grp["ids"]
+
     def merge(self, exact_all, ids_all, k: int):
         import torch
         W, B, _ = exact_all.shape
@@ -121,6 +147,42 @@ class ShardedSearcher:
                 self.dist.all_gather_into_tensor(outp, inp, group=self.group)
         scores, gids = self.backend.merge_packed(flat, lane)
         return scores, gids, lane["flags"]
+
+    def search_group(self, queries, k: int, workspaces, streams):
+        """L batches at once (product backend only): batch i is scanned on streams[i] with
+        workspaces[i]; their per-shard top-k travel in ONE all-gather and are merged by one launch
+        on the CURRENT stream.  -> (scores f32 [L,B,k], global ids i64 [L,B,k], flags i32 [L,B]);
+        the tensors are reused by the next call with the same shape.  Measured on one GPU with a
+        one-rank collective this is SLOWER than one all-gather per batch (58 vs 50 us/step at
+        125 k-row shards: consecutive groups serialise on the shared send / receive buffers);
+        kept for the real multi-GPU runs, where the collective itself is dearer, to try."""
+        import torch
+        L = len(queries)
+        B = queries[0].shape[0]
+        key = ("group", L, B, k)
+        grp = self._lanes.get(key)
+        if grp is None:
+            grp = self._lanes[key] = self.backend.new_group(L, B, k, self.world)
+        main = torch.cuda.current_stream()
+        for i, q in enumerate(queries):
+            with torch.cuda.stream(streams[i]):
+                self.backend.local_topk_group(q, k, self.row_base, grp, i, workspaces[i])
+            main.wait_stream(streams[i])
+        if self.world == 1 and not self.force_collective:
+            recv = grp["send"]
+        else:
+            recv = grp["recv"]
+            inp, outp = grp["send"].view(L * 2 * B, k), recv.view(self.world * L * 2 * B, k)
+            if self.dist.get_backend(self.group) == "gloo":   # rehearsal path: stage through the host
+                host = outp.cpu()
+                self.dist.all_gather_into_tensor(host, inp.cpu(), group=self.group)
+                outp.copy_(host)
+            else:
+                self.dist.all_gather_into_tensor(outp, inp, group=self.group)
+        scores, gids = self.backend.merge_group(recv, grp)
+        for st in streams:            # the lanes' next scans overwrite `send`: they follow the collective
+            st.wait_stream(main)
+        return scores, gids, grp["flags"]
 
     @staticmethod
     def shard_bounds(n_total: int, world: int, rank: int):

@@ -63,3 +63,29 @@ def test_merge_shards_with_short_shards(gpu_device):
     os_, oi = c_oracle.search(q16, c, k)
     assert np.array_equal(gids.cpu().numpy(), oi)
     assert np.array_equal(scores.cpu().numpy(), os_.astype(np.float32))
+
+
+def test_search_group_equals_single_searches(gpu_device):
+    """Several batches in flight whose per-shard top-k share one collective
+    (ShardedSearcher.search_group, rf_merge_shards_group) answer exactly like one search per
+    batch -- world-size-1 form of the path bench.py takes at N > 1."""
+    import torch
+    from rag_fin_amd.sharded import HipShardBackend, ShardedSearcher
+    from rag_fin_amd.store import GpuIndex
+    n, d, b, k, L = 60_000, 384, 64, 10, 3
+    c = osearch.synth_unit_rows(n, d, 21)
+    ix = GpuIndex(d, n, gpu_device)
+    ix.add(torch.from_numpy(c).to(gpu_device))
+    qs = [torch.from_numpy(osearch.synth_unit_rows(b, d, 30 + i)).to(gpu_device) for i in range(L)]
+    searcher = ShardedSearcher(HipShardBackend(ix), row_base=1000)
+    wss = [ix.workspace] + [ix.new_workspace() for _ in range(L - 1)]
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(L)]
+    for _ in range(2):      # second round reuses the group buffers
+        scores, ids, flags = searcher.search_group(qs, k, wss, streams)
+        torch.cuda.synchronize()
+        assert int(flags.abs().sum()) == 0
+        for i in range(L):
+            s1, i1, e1, _ = ix.search_raw(qs[i], k, id_base=1000, want_exact=True)
+            assert torch.equal(ids[i], i1) and torch.equal(scores[i], s1)
+            os_, oi = c_oracle.search(qs[i].cpu().numpy(), c, k)
+            assert np.array_equal(ids[i].cpu().numpy() - 1000, oi)

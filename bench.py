@@ -137,6 +137,23 @@ def main():
     searcher = ShardedSearcher(HipShardBackend(index), row_base=row_base) if (world > 1 or force_sharded) else None
     if force_sharded:
         searcher.force_collective = True
+    direct_rccl = False
+    if searcher is not None and os.environ.get("RAGFIN_DIRECT_RCCL", "1") == "1" and \
+            (force_sharded or os.environ.get("RAGFIN_DIST_BACKEND", "nccl") == "nccl"):
+        # the step's all-gather straight through librccl (ctypes) on the lane's stream: torch's wrapper
+        # costs ~25 us of host time per call, which bounds the strong-scaled job from 4 GPUs on
+        try:
+            direct_rccl = searcher.enable_direct_rccl(dev)
+        except Exception as e:   # fall back to torch.distributed -- on EVERY rank (agreed below)
+            print(f"[bench] direct RCCL unavailable on rank {rank}: {e}", file=sys.stderr)
+            direct_rccl = False
+        if world > 1:
+            ok = torch.tensor([1 if direct_rccl else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and searcher.rccl is not None:
+                searcher.rccl.destroy()
+                searcher.rccl = None
+            direct_rccl = bool(int(ok.item()))
     # `streams` batches in flight: each has its own HIP stream, workspace and output
     # buffers; the corpus index is immutable and shared.  Step i runs on lane i % lanes.
     max_lanes = max(1, args.streams)
@@ -241,6 +258,8 @@ def main():
                        else f"{rows_total} x {dim}-d fp16 corpus ({rows} rows per GPU), batch-{B}, top-{k}",
                        "rows_per_gpu": rows, "rows_total": rows_total, "dim": dim, "batch": B,
                        "topk": k, "batches_in_flight": n_lanes,
+                       "collective_api": ("ncclAllGather via ctypes" if direct_rccl else "torch.distributed")
+                       if searcher is not None else None,
                        "collective": ("none" if searcher is None else
                                       ("one all-gather per %d batches" % n_lanes if (n_lanes > 1 and args.group)
                                        else "one all-gather per batch")),
@@ -336,6 +355,9 @@ def main():
         os.dup2(2, 1)
     if world > 1:
         dist.barrier()
+    if searcher is not None and searcher.rccl is not None:
+        torch.cuda.synchronize()
+        searcher.rccl.destroy()
     if world > 1 or force_sharded:
         dist.destroy_process_group()
 

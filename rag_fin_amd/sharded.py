@@ -122,6 +122,14 @@ class ShardedSearcher:
         self._lanes = {}
         # world 1 normally skips the collective; set to run it anyway (overhead measurements)
         self.force_collective = False
+        self.rccl = None   # enable_direct_rccl(): ncclAllGather through ctypes instead of torch.distributed
+
+    def enable_direct_rccl(self, device):
+        """Own RCCL communicator for the per-step all-gather (rag_fin_amd/rccl.py); every rank of
+        the group must call this at the same point.  Returns True when it is in use."""
+        from .rccl import RcclComm
+        self.rccl = RcclComm(self.rank, self.world, device, self.group)
+        return True
 
     def _search_lane(self, q16, k: int, workspace):
         """Product path (HipShardBackend): per-(workspace, B, k) preallocated buffers; the
@@ -138,7 +146,9 @@ class ShardedSearcher:
         else:
             flat = lane["flat"]
             inp, outp = lane["packed"].view(2 * B, k), flat.view(self.world * 2 * B, k)
-            if self.dist.get_backend(self.group) == "gloo":
+            if self.rccl is not None:
+                self.rccl.all_gather_i64(inp.data_ptr(), outp.data_ptr(), 2 * B * k, _lib.current_stream_ptr())
+            elif self.dist.get_backend(self.group) == "gloo":
                 # rehearsal path (gloo has no device all-gather): stage through the host
                 host = outp.cpu()
                 self.dist.all_gather_into_tensor(host, inp.cpu(), group=self.group)

@@ -154,6 +154,10 @@ def main():
                 searcher.rccl.destroy()
                 searcher.rccl = None
             direct_rccl = bool(int(ok.item()))
+    # N > 1 (or the one-rank rehearsal) with the direct RCCL binding: a step is three bare ctypes
+    # enqueues on the lane's stream (ShardedSearcher.search_on), no torch call on the hot path
+    bare_enqueues = searcher is not None and (direct_rccl or (world == 1 and not force_sharded)) and \
+        os.environ.get("RAGFIN_BARE_ENQUEUES", "1") == "1"
     # `streams` batches in flight: each has its own HIP stream, workspace and output
     # buffers; the corpus index is immutable and shared.  Step i runs on lane i % lanes.
     max_lanes = max(1, args.streams)
@@ -181,6 +185,10 @@ def main():
         def step():
             lane = lanes[counter[0] % n_lanes]
             counter[0] += 1
+            if searcher is not None and bare_enqueues:
+                lane["res"] = searcher.search_on(q, k, lane["ws"], lane["stream"])
+                res[0] = lane["res"]
+                return
             with torch.cuda.stream(lane["stream"]):
                 if searcher is not None:
                     lane["res"] = searcher.search(q, k, workspace=lane["ws"])

@@ -131,6 +131,40 @@ class ShardedSearcher:
         self.rccl = RcclComm(self.rank, self.world, device, self.group)
         return True
 
+    def search_on(self, q16, k: int, workspace, stream):
+        """The step as three bare enqueues on `stream` (a torch.cuda.Stream of this rank's device):
+        rf_search -> ncclAllGather -> rf_merge_shards_packed, all through ctypes with cached
+        pointers -- no torch call on the hot path, no current-stream switch.  Needs
+        enable_direct_rccl() when world > 1.  q16 must be a contiguous fp16 [B, dim] tensor on the
+        device that stays alive until the step has run; same return as search()."""
+        B = q16.shape[0]
+        key = ("on", workspace.data_ptr() if workspace is not None else 0, B, k, stream.cuda_stream)
+        st = self._lanes.get(key)
+        if st is None:
+            lane = self.backend.new_lane(B, k, self.world)
+            ws = workspace if workspace is not None else self.backend.index.workspace
+            packed, flat = lane["packed"], lane["flat"]
+            st = self._lanes[key] = dict(
+                lane=lane, sp=c_void_p(stream.cuda_stream), ws=ws.data_ptr(),
+                scores_local=lane["local_scores"].data_ptr(), ids=packed[1].data_ptr(), exact=packed[0].data_ptr(),
+                flags=lane["flags"].data_ptr(), packed=packed.data_ptr(), flat=flat.data_ptr(),
+                out_s=lane["scores"].data_ptr(), out_i=lane["ids"].data_ptr())
+        ix = self.backend.index
+        ix.enqueue_search(q16.data_ptr(), B, k, self.row_base, st["scores_local"], st["ids"], st["exact"],
+                          st["flags"], st["ws"], st["sp"])
+        if self.world == 1 and not self.force_collective:
+            src = st["packed"]
+        else:
+            if self.rccl is None:
+                raise RuntimeError("search_on needs enable_direct_rccl() when the job has more than one rank")
+            self.rccl.all_gather_i64(st["packed"], st["flat"], 2 * B * k, st["sp"])
+            src = st["flat"]
+        rc = self.backend.lib.rf_merge_shards_packed(src, self.world, B, k, st["out_s"], st["out_i"], st["sp"])
+        if rc:
+            _lib.check(rc)
+        lane = st["lane"]
+        return lane["scores"], lane["ids"], lane["flags"]
+
     def _search_lane(self, q16, k: int, workspace):
         """Product path (HipShardBackend): per-(workspace, B, k) preallocated buffers; the
         returned tensors are those buffers -- consume them before the same lane searches

@@ -133,8 +133,9 @@ class GpuIndex:
         return torch.zeros(self.workspace_bytes, dtype=torch.uint8, device=self.device)
 
     def search_raw(self, q16, k: int, id_base: int = 0, want_exact: bool = False, out=None,
-                   workspace=None):
-        """Enqueue rf_search on the current stream; no host sync.  Returns
+                   workspace=None, stream_ptr=None):
+        """Enqueue rf_search on the current stream (or on `stream_ptr`, a c_void_p holding a
+        hipStream_t of this device); no host sync.  Returns
         (scores f32 [B,k], ids i64 [B,k], exact f64 [B,k] | None, flags u32 [B])."""
         torch = _torch()
         if q16.dtype != torch.float16 or q16.dim() != 2 or q16.shape[1] != self.dim:
@@ -155,8 +156,18 @@ class GpuIndex:
                 c_void_p(ids.data_ptr()), c_void_p(exact.data_ptr()) if exact is not None else None,
                 c_void_p(flags.data_ptr()),
                 c_void_p((workspace if workspace is not None else self.workspace).data_ptr()),
-                self.workspace_bytes, _lib.current_stream_ptr()))
+                self.workspace_bytes, stream_ptr if stream_ptr is not None else _lib.current_stream_ptr()))
         return scores, ids, exact, flags
+
+    def enqueue_search(self, q_ptr: int, B: int, k: int, id_base: int, scores_ptr: int, ids_ptr: int,
+                       exact_ptr: int, flags_ptr: int, workspace_ptr: int, stream_ptr):
+        """The bare rf_search enqueue for callers that own every buffer (the sharded step: no
+        tensor checks, no allocations, no stream / device context).  The caller guarantees that
+        this index's device is the thread's current HIP device."""
+        rc = self.lib.rf_search(self.handle, q_ptr, B, k, id_base, scores_ptr, ids_ptr, exact_ptr, flags_ptr,
+                                workspace_ptr, self.workspace_bytes, stream_ptr)
+        if rc:
+            _lib.check(rc)
 
     def search_profile(self, q16, k: int):
         """rf_search_profile: per-stage HIP-event times in ms (synchronises)."""

@@ -89,3 +89,30 @@ def test_search_group_equals_single_searches(gpu_device):
             assert torch.equal(ids[i], i1) and torch.equal(scores[i], s1)
             os_, oi = c_oracle.search(qs[i].cpu().numpy(), c, k)
             assert np.array_equal(ids[i].cpu().numpy() - 1000, oi)
+
+
+def test_search_on_bare_enqueues_equal_search(gpu_device):
+    """ShardedSearcher.search_on (the bench's N > 1 step: three ctypes enqueues on an explicit
+    stream with cached pointers) returns what search() returns, on side streams and repeatedly."""
+    import torch
+    from rag_fin_amd.sharded import HipShardBackend, ShardedSearcher
+    from rag_fin_amd.store import GpuIndex
+    n, d, b, k = 40_000, 384, 64, 10
+    c = osearch.synth_unit_rows(n, d, 51)
+    ix = GpuIndex(d, n, gpu_device)
+    ix.add(torch.from_numpy(c).to(gpu_device))
+    searcher = ShardedSearcher(HipShardBackend(ix), row_base=7)
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(device=gpu_device)]
+    wss = [ix.workspace, ix.new_workspace()]
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        q16 = osearch.synth_unit_rows(b, d, 60 + rnd)
+        q = torch.from_numpy(q16).to(gpu_device)
+        torch.cuda.synchronize()
+        outs = [searcher.search_on(q, k, wss[i], streams[i]) for i in range(2)]
+        torch.cuda.synchronize()
+        os_, oi = c_oracle.search(q16, c, k)
+        for s_, i_, f_ in outs:
+            assert int(f_.abs().sum()) == 0
+            assert np.array_equal(i_.cpu().numpy() - 7, oi)
+            assert np.array_equal(s_.cpu().numpy(), os_.astype(np.float32))

@@ -171,6 +171,12 @@ def main():
                  torch.empty((B, k), dtype=torch.float64, device=dev),
                  torch.empty((B,), dtype=torch.int32, device=dev))))
     out = lanes[0]["out"]
+    if searcher is None and os.environ.get("RAGFIN_BARE_ENQUEUES", "1") == "1":
+        from ctypes import c_void_p
+        for l in lanes:
+            o = l["out"]
+            l["bare"] = (q.data_ptr(), B, k, 0, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+                         l["ws"].data_ptr(), c_void_p(l["stream"].cuda_stream))
 
     def barrier():
         if world > 1:
@@ -188,6 +194,9 @@ def main():
             if searcher is not None and bare_enqueues:
                 lane["res"] = searcher.search_on(q, k, lane["ws"], lane["stream"])
                 res[0] = lane["res"]
+                return
+            if searcher is None and lane.get("bare") is not None:
+                index.enqueue_search(*lane["bare"])   # one ctypes call, cached pointers, the lane's stream
                 return
             with torch.cuda.stream(lane["stream"]):
                 if searcher is not None:

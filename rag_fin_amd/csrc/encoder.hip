@@ -23,8 +23,10 @@
 //   k_pool_norm     mean over the sequence, L2-normalise                      (K7)
 #include "rf_internal.h"
 #include "lds_ring.h"
+#include <mutex>
 #include <new>
 #include <stdlib.h>
+#include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -52,6 +54,18 @@ struct rf_encoder {
   const uint4* ao_t;         // tiled [L][H/32][H/16][64]
   const uint4* ff1_t;        // tiled [L][I/32][H/16][64]
   const uint4* ff2_t;        // tiled [L][H/32][I/16][64]
+  // small batches: the ~45 launches of a forward as ONE hipGraph per (shape, buffers) -- a
+  // 12-token query is launch-bound (5 us of host time per launch against 2-5 us of kernel)
+  struct Graph {
+    int B, T;
+    const void *ids, *lens;
+    void *o16, *o32, *ws;
+    hipGraphExec_t exec;   // nullptr: seen once (the plain run also sets the kernels' attributes)
+    bool dead;             // capture failed for this key: stay on plain launches
+  };
+  mutable std::vector<Graph> graphs;
+  mutable hipStream_t cap_stream = nullptr;
+  mutable std::mutex mu;
 };
 
 static bool cfg_supported(const rf_encoder_config* c) {
@@ -125,6 +139,11 @@ extern "C" int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cf
 }
 
 extern "C" int rf_encoder_destroy(rf_encoder_t* enc) {
+  if (enc) {
+    for (auto& g : enc->graphs)
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (enc->cap_stream) (void)hipStreamDestroy(enc->cap_stream);
+  }
   delete enc;
   return RF_OK;
 }
@@ -1131,6 +1150,63 @@ static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Floa
                        N, m_ptr, res, g, b, eps);
 }
 
+int rf_tuning_encode_graph = -1;   // small batches through a cached hipGraph (RF_ENCODE_GRAPH=0 / rf_set_tuning to disable)
+static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int T,
+                          void* out_f16_dev, float* out_f32_dev, void* workspace_dev, hipStream_t st);
+
+// First call with a (shape, buffers) key: plain launches.  Second: the same launch sequence is
+// captured on a private stream, instantiated and replayed on the caller's stream; later calls
+// replay.  Returns RF_ERR_UNSUPPORTED when the caller should use plain launches.
+static int encode_graphed(const rf_encoder_t* enc, const int32_t* ids, const int32_t* lens, int B, int T, void* o16,
+                          float* o32, void* wsp, hipStream_t st) {
+  if (rf_tuning_encode_graph < 0) {
+    const char* v = getenv("RF_ENCODE_GRAPH");
+    rf_tuning_encode_graph = (v && v[0] == '0') ? 0 : 1;
+    if (!rf_tuning_encode_graph) return RF_ERR_UNSUPPORTED;
+  }
+  std::lock_guard<std::mutex> lock(enc->mu);
+  rf_encoder::Graph* g = nullptr;
+  for (auto& e : enc->graphs)
+    if (e.B == B && e.T == T && e.ids == ids && e.lens == lens && e.o16 == o16 && e.o32 == (void*)o32 && e.ws == wsp) {
+      g = &e;
+      break;
+    }
+  if (!g) {
+    if (enc->graphs.size() >= 32) {   // evict the oldest
+      if (enc->graphs.front().exec) (void)hipGraphExecDestroy(enc->graphs.front().exec);
+      enc->graphs.erase(enc->graphs.begin());
+    }
+    enc->graphs.push_back(rf_encoder::Graph{B, T, ids, lens, o16, (void*)o32, wsp, nullptr, false});
+    return RF_ERR_UNSUPPORTED;
+  }
+  if (g->dead) return RF_ERR_UNSUPPORTED;
+  if (!g->exec) {
+    if (!enc->cap_stream && hipStreamCreateWithFlags(&enc->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+      g->dead = true;
+      return RF_ERR_UNSUPPORTED;
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(enc->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      g->dead = true;
+      return RF_ERR_UNSUPPORTED;
+    }
+    const int rc = encode_enqueue(enc, ids, lens, B, T, o16, o32, wsp, enc->cap_stream);
+    const hipError_t e1 = hipStreamEndCapture(enc->cap_stream, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (rc != RF_OK || e1 != hipSuccess || !graph ||
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      g->dead = true;
+      return RF_ERR_UNSUPPORTED;
+    }
+    (void)hipGraphDestroy(graph);
+    g->exec = exec;
+  }
+  RF_HIP(hipGraphLaunch(g->exec, st));
+  return RF_OK;
+}
+
 extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev,
                          int B, int T, void* out_f16_dev, float* out_f32_dev, void* workspace_dev,
                          size_t workspace_bytes, void* stream) {
@@ -1151,6 +1227,15 @@ extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const 
     return RF_ERR_CAPACITY;
   }
   hipStream_t st = (hipStream_t)stream;
+  if ((size_t)B * T <= SM_MAX_TOK && rf_tuning_encode_graph) {
+    const int rc = encode_graphed(enc, ids_dev, lens_dev, B, T, out_f16_dev, out_f32_dev, workspace_dev, st);
+    if (rc != RF_ERR_UNSUPPORTED) return rc;   // RF_ERR_UNSUPPORTED here = "take the plain path"
+  }
+  return encode_enqueue(enc, ids_dev, lens_dev, B, T, out_f16_dev, out_f32_dev, workspace_dev, st);
+}
+
+static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int T,
+                          void* out_f16_dev, float* out_f32_dev, void* workspace_dev, hipStream_t st) {
   const rf_encoder_config& c = enc->cfg;
   const rf_encoder_weights& w = enc->w;
   const int I = c.intermediate, L = c.layers;

@@ -321,7 +321,7 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t st) {
 
 // ---- tuning knobs (rf_set_tuning / environment at first use) ---------------------------
 extern int rf_tuning_fused;  // api.hip
-extern int rf_tuning_ffn2_ntb, rf_tuning_k384_ntb;
+extern int rf_tuning_ffn2_ntb, rf_tuning_k384_ntb, rf_tuning_encode_graph;
 extern int rf_tuning_linear_dma, rf_tuning_linear_small, rf_debug_epi, rf_debug_linear_flags;   // encoder.hip
 extern int rf_tuning_wide_variant, rf_tuning_wide_nt, rf_tuning_wide_dbg, rf_tuning_wide_sample_pairs;  // scan_wide.hip
 struct ScanTuning {
@@ -347,6 +347,7 @@ extern "C" int rf_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "sample_bpw") && value >= 1 && value <= 8) t.sample_bpw = value;
   else if (!strcmp(key, "qreg") && (value == 0 || value == 1)) t.qreg = value;
   else if (!strcmp(key, "linear_dma") && value >= 0 && value <= 3) rf_tuning_linear_dma = value;
+  else if (!strcmp(key, "encode_graph") && (value == 0 || value == 1)) rf_tuning_encode_graph = value;
   else if (!strcmp(key, "k384_ntb") && (value == 2 || value == 4)) rf_tuning_k384_ntb = value;
   else if (!strcmp(key, "ffn2_ntb") && (value == 2 || value == 4)) rf_tuning_ffn2_ntb = value;
   else if (!strcmp(key, "linear_small") && (value == 0 || value == 1)) rf_tuning_linear_small = value;

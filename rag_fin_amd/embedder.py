@@ -162,16 +162,29 @@ class Embedder:
         """ids int32 [B, T], lens int32 [B] (tensors or arrays) -> [B, 384] tensor on
         the device (fp16 by default: exactly what CorpusStore stores)."""
         torch = _torch()
-        ids = torch.as_tensor(ids, dtype=torch.int32).to(self.device).contiguous()
-        lens = torch.as_tensor(lens, dtype=torch.int32).to(self.device).contiguous()
+        ids = torch.as_tensor(ids, dtype=torch.int32)
+        lens = torch.as_tensor(lens, dtype=torch.int32)
         if ids.dim() != 2 or lens.shape != (ids.shape[0],):
             raise ValueError("encode_ids expects ids [B, T] and lens [B]")
         B, T = ids.shape
         if T > self.cfg["max_position"]:
             raise ValueError(f"T={T} exceeds max_position {self.cfg['max_position']}")
         want32 = out_dtype in ("float32", np.float32)
-        out16 = None if want32 else torch.empty((B, self.dim), dtype=torch.float16, device=self.device)
-        out32 = torch.empty((B, self.dim), dtype=torch.float32, device=self.device) if want32 else None
+        small = B * T <= self.SMALL_SLOTS
+        if small:
+            # a query-sized batch: fixed staging buffers, so that rf_encode sees the same pointers call
+            # after call and replays its cached hipGraph instead of ~45 launches (the result is cloned)
+            sb = self._small_buffers()
+            sb["ids"][:B * T].copy_(ids.reshape(-1), non_blocking=True)
+            sb["lens"][:B].copy_(lens, non_blocking=True)
+            ids, lens = sb["ids"], sb["lens"]
+            out16 = None if want32 else sb["o16"]
+            out32 = sb["o32"] if want32 else None
+        else:
+            ids = ids.to(self.device).contiguous()
+            lens = lens.to(self.device).contiguous()
+            out16 = None if want32 else torch.empty((B, self.dim), dtype=torch.float16, device=self.device)
+            out32 = torch.empty((B, self.dim), dtype=torch.float32, device=self.device) if want32 else None
         with torch.cuda.device(self.device):
             ws = self._workspace(self.lib.rf_encode_workspace_bytes(self.handle, B, T))
             _lib.check(self.lib.rf_encode(self.handle, c_void_p(ids.data_ptr()), c_void_p(lens.data_ptr()),
@@ -179,7 +192,24 @@ class Embedder:
                                           c_void_p(out32.data_ptr()) if out32 is not None else None,
                                           c_void_p(ws.data_ptr()), ws.numel(),
                                           _lib.current_stream_ptr()))
-        return out32 if want32 else out16
+        res = out32 if want32 else out16
+        return res[:B].clone() if small else res
+
+    SMALL_SLOTS = 1024   # = SM_MAX_TOK of csrc/encoder.hip: the small-batch GEMM path / hipGraph replay
+
+    def _small_buffers(self):
+        torch = _torch()
+        if getattr(self, "_sb", None) is None:
+            n = self.SMALL_SLOTS
+            self._sb = {"ids": torch.zeros(n, dtype=torch.int32, device=self.device),
+                        "lens": torch.zeros(n, dtype=torch.int32, device=self.device),
+                        "o16": torch.zeros((n, self.dim), dtype=torch.float16, device=self.device),
+                        "o32": torch.zeros((n, self.dim), dtype=torch.float32, device=self.device)}
+            # workspace large enough for every small shape: its pointer must not move either
+            with torch.cuda.device(self.device):
+                self._workspace(max(self.lib.rf_encode_workspace_bytes(self.handle, n, 1),
+                                    self.lib.rf_encode_workspace_bytes(self.handle, max(1, n // 256), 256)))
+        return self._sb
 
     def encode_to_device(self, sentences, batch_tokens: int = 65536):
         """Tokenise, bucket by length, encode; returns fp16 [n, 384] on the device in

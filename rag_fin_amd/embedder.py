@@ -16,6 +16,7 @@ from __future__ import annotations
 import ctypes
 import json
 import os
+import threading
 from ctypes import c_void_p
 
 import numpy as np
@@ -101,6 +102,7 @@ class Embedder:
                                                   nbytes, self.device.index, _lib.current_stream_ptr()))
         self.handle = h
         self._ws = None
+        self._small_lock = threading.Lock()
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -172,19 +174,12 @@ class Embedder:
         want32 = out_dtype in ("float32", np.float32)
         small = B * T <= self.SMALL_SLOTS
         if small:
-            # a query-sized batch: fixed staging buffers, so that rf_encode sees the same pointers call
-            # after call and replays its cached hipGraph instead of ~45 launches (the result is cloned)
-            sb = self._small_buffers()
-            sb["ids"][:B * T].copy_(ids.reshape(-1), non_blocking=True)
-            sb["lens"][:B].copy_(lens, non_blocking=True)
-            ids, lens = sb["ids"], sb["lens"]
-            out16 = None if want32 else sb["o16"]
-            out32 = sb["o32"] if want32 else None
-        else:
-            ids = ids.to(self.device).contiguous()
-            lens = lens.to(self.device).contiguous()
-            out16 = None if want32 else torch.empty((B, self.dim), dtype=torch.float16, device=self.device)
-            out32 = torch.empty((B, self.dim), dtype=torch.float32, device=self.device) if want32 else None
+            with self._small_lock:   # the staging buffers are shared: enqueue copy + forward + clone as one unit
+                return self._encode_small(ids, lens, B, T, want32)
+        return self._encode_large(ids, lens, B, T, want32)
+
+    def _launch(self, ids, lens, B, T, out16, out32):
+        torch = _torch()
         with torch.cuda.device(self.device):
             ws = self._workspace(self.lib.rf_encode_workspace_bytes(self.handle, B, T))
             _lib.check(self.lib.rf_encode(self.handle, c_void_p(ids.data_ptr()), c_void_p(lens.data_ptr()),
@@ -192,8 +187,28 @@ class Embedder:
                                           c_void_p(out32.data_ptr()) if out32 is not None else None,
                                           c_void_p(ws.data_ptr()), ws.numel(),
                                           _lib.current_stream_ptr()))
+
+    def _encode_large(self, ids, lens, B, T, want32):
+        torch = _torch()
+        ids = ids.to(self.device).contiguous()
+        lens = lens.to(self.device).contiguous()
+        out16 = None if want32 else torch.empty((B, self.dim), dtype=torch.float16, device=self.device)
+        out32 = torch.empty((B, self.dim), dtype=torch.float32, device=self.device) if want32 else None
+        self._launch(ids, lens, B, T, out16, out32)
+        return out32 if want32 else out16
+
+    def _encode_small(self, ids, lens, B, T, want32):
+        # a query-sized batch: fixed staging buffers, so that rf_encode sees the same pointers call
+        # after call and replays its cached hipGraph instead of ~45 launches (the result is cloned)
+        sb = self._small_buffers()
+        sb["ids"][:B * T].copy_(ids.reshape(-1), non_blocking=True)
+        sb["lens"][:B].copy_(lens, non_blocking=True)
+        ids, lens = sb["ids"], sb["lens"]
+        out16 = None if want32 else sb["o16"]
+        out32 = sb["o32"] if want32 else None
+        self._launch(ids, lens, B, T, out16, out32)
         res = out32 if want32 else out16
-        return res[:B].clone() if small else res
+        return res[:B].clone()
 
     SMALL_SLOTS = 1024   # = SM_MAX_TOK of csrc/encoder.hip: the small-batch GEMM path / hipGraph replay
 

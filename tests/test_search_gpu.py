@@ -218,6 +218,61 @@ def test_full_size_1m_properties(gpu_device, dim):
     assert torch.equal(i3, i[5:6]) and torch.equal(e3, e[5:6])
 
 
+def test_full_size_1m_batch256_properties(gpu_device):
+    """BASELINE.json configs[2] itself (1M x 384, batch 256 -> one wide LDS-DMA sweep): size-
+    independent checks.  (1) planted needles rank first with score ||q||^2; (2) the 256-query
+    result equals the same queries answered by 64-query sweeps (a different kernel) bit for
+    bit; (3) a subset equals the exhaustive fp64 kernel; (4) order and uniqueness."""
+    import torch
+    n, dim, B = 1_000_000, 384, 256
+    gen = torch.Generator(device=gpu_device).manual_seed(4321)
+    c = torch.randn((n, dim), generator=gen, device=gpu_device, dtype=torch.float32)
+    c = (c / c.norm(dim=1, keepdim=True)).half()
+    q = torch.randn((B, dim), generator=gen, device=gpu_device, dtype=torch.float32)
+    q = (q / q.norm(dim=1, keepdim=True)).half()
+    plant = torch.arange(B, device=gpu_device) * 3_907 + 11
+    c[plant] = q
+    from rag_fin_amd.store import GpuIndex
+    ix = GpuIndex(dim, n, gpu_device)
+    ix.add(c)
+    s, i, e, f = ix.search_raw(q, 10, want_exact=True)
+    torch.cuda.synchronize()
+    assert int(f.abs().sum()) == 0
+    assert torch.equal(i[:, 0], plant)
+    assert torch.allclose(e[:, 0], (q.double() ** 2).sum(1), rtol=0, atol=1e-12)
+    assert bool((e[:, 1:] <= e[:, :-1]).all())
+    assert all(len(set(r.tolist())) == 10 for r in i.cpu())
+    parts = [ix.search_raw(q[a:a + 64].contiguous(), 10, want_exact=True) for a in range(0, B, 64)]
+    assert torch.equal(i, torch.cat([p[1] for p in parts])) and torch.equal(e, torch.cat([p[2] for p in parts]))
+    s2, i2, e2 = ix.search_exhaustive(q[100:106].contiguous(), 10, want_exact=True)
+    assert torch.equal(i2, i[100:106]) and torch.equal(e2, e[100:106])
+
+
+def test_config5_shard_size_768_properties(gpu_device):
+    """One GPU's shard of BASELINE.json configs[4] (1.25M x 768): planted needles, order,
+    agreement with the exhaustive kernel, and global ids through id_base."""
+    import torch
+    n, dim, B = 1_250_000, 768, 64
+    gen = torch.Generator(device=gpu_device).manual_seed(99)
+    c = torch.randn((n, dim), generator=gen, device=gpu_device, dtype=torch.float32)
+    c = (c / c.norm(dim=1, keepdim=True)).half()
+    q = torch.randn((B, dim), generator=gen, device=gpu_device, dtype=torch.float32)
+    q = (q / q.norm(dim=1, keepdim=True)).half()
+    plant = torch.arange(B, device=gpu_device) * 19_001 + 3
+    c[plant] = q
+    from rag_fin_amd.store import GpuIndex
+    ix = GpuIndex(dim, n, gpu_device)
+    ix.add(c)
+    base = 3 * n                                   # rank 3 of a row-sharded job
+    s, i, e, f = ix.search_raw(q, 10, id_base=base, want_exact=True)
+    torch.cuda.synchronize()
+    assert int(f.abs().sum()) == 0
+    assert torch.equal(i[:, 0], plant + base)
+    assert bool((e[:, 1:] <= e[:, :-1]).all())
+    s2, i2, e2 = ix.search_exhaustive(q[:4].contiguous(), 10, id_base=base, want_exact=True)
+    assert torch.equal(i2, i[:4]) and torch.equal(e2, e[:4])
+
+
 @pytest.mark.parametrize("n,b,k", [(40_000, 256, 10), (25_000, 300, 10), (3_000, 100, 10), (70_000, 65, 64),
                                    (8_193, 129, 5)])
 def test_wide_sweep_parity(gpu_device, n, b, k):

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Soak test: the LDS-DMA kernels rely on hand-counted vmcnt / lgkmcnt waits and raw barriers;
+a misplaced wait shows up as a RARE wrong tile, not as a failing unit test.  Repeat the wide
+sweep (batch 256) and the large-batch encoder many times on changing inputs and compare every
+result with an independent path (64-query sweeps of a different kernel / the direct-load GEMMs)
+or with the first run of the same input (bitwise)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--search-iters", type=int, default=1500)
+    ap.add_argument("--encode-iters", type=int, default=60)
+    args = ap.parse_args()
+    import torch
+    from oracle import encoder as oenc
+    from rag_fin_amd import _lib
+    from rag_fin_amd.embedder import Embedder
+    from rag_fin_amd.store import GpuIndex
+    dev = torch.device("cuda:0")
+    lib = _lib.load_library()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    n, dim = 300_000, 384
+    c = torch.randn((n, dim), generator=gen, device=dev)
+    c = (c / c.norm(dim=1, keepdim=True)).half()
+    ix = GpuIndex(dim, n, dev)
+    ix.add(c)
+    bad = 0
+    for it in range(args.search_iters):
+        q = torch.randn((256, dim), generator=gen, device=dev)
+        q = (q / q.norm(dim=1, keepdim=True)).half()
+        s, i, e, f = ix.search_raw(q, 10, want_exact=True)
+        if it % 25 == 0:   # independent path: four 64-query sweeps (k_scan, queries in LDS, register ring)
+            parts = [ix.search_raw(q[a:a + 64].contiguous(), 10, want_exact=True) for a in range(0, 256, 64)]
+            ok = torch.equal(i, torch.cat([p[1] for p in parts])) and torch.equal(e, torch.cat([p[2] for p in parts]))
+        else:              # same input again: bitwise repeatability
+            s2, i2, e2, f2 = ix.search_raw(q, 10, want_exact=True)
+            ok = torch.equal(i, i2) and torch.equal(e, e2)
+        ok = ok and int(f.abs().sum()) == 0
+        bad += 0 if ok else 1
+        if it % 250 == 0:
+            print(f"search iter {it}: mismatches so far {bad}", flush=True)
+    print(f"wide sweep: {args.search_iters} iterations, {bad} mismatches")
+    cfg = dict(oenc.MINILM_L6)
+    emb = Embedder(oenc.random_weights(cfg, 0), cfg, device=dev)
+    rng = np.random.default_rng(1)
+    ebad = 0
+    for it in range(args.encode_iters):
+        B, T = 240, 256                                  # 61 440 slots: 256-token LDS-DMA workgroups
+        lens = rng.integers(40, T + 1, B).astype(np.int32)
+        ids = rng.integers(1000, cfg["vocab_size"], (B, T)).astype(np.int32)
+        a = emb.encode_ids(ids, lens, out_dtype="float32")
+        b = emb.encode_ids(ids, lens, out_dtype="float32")
+        ok = torch.equal(a, b)
+        if it % 10 == 0:
+            _lib.check(lib.rf_set_tuning(b"linear_dma", 0))
+            d = emb.encode_ids(ids, lens, out_dtype="float32")
+            _lib.check(lib.rf_set_tuning(b"linear_dma", 1))
+            ok = ok and float((a - d).abs().max()) < 2e-3
+        ebad += 0 if ok else 1
+    print(f"encoder (LDS-DMA GEMMs): {args.encode_iters} iterations, {ebad} mismatches")
+    sys.exit(1 if (bad or ebad) else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -103,6 +103,7 @@ class Embedder:
         self.handle = h
         self._ws = None
         self._small_lock = threading.Lock()
+        self._copy_stream = None
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -236,32 +237,57 @@ class Embedder:
         if isinstance(sentences, str):
             sentences = [sentences]
         # text -> ids through the native tokenizer (csrc/tokenizer.cpp, one thread per host core);
-        # a tokenizer object without batch_native (a test double) takes the per-sentence path
+        # a tokenizer object without batch_native (a test double) takes the per-sentence path.
+        # Large inputs go in chunks of `chunk_texts`: rf_encode only ENQUEUES, so while the GPU works
+        # through one chunk's buckets the host is already tokenising the next chunk.
         sentences = list(sentences)
-        if hasattr(self.tokenizer, "batch_native"):
-            all_ids, all_lens = self.tokenizer.batch_native(sentences, self.max_seq_length)
-        else:
-            rows = [self.tokenizer.encode(s, self.max_seq_length) for s in sentences]
-            all_lens = np.array([len(r) for r in rows], dtype=np.int32)
-            all_ids = np.full((len(rows), max(int(all_lens.max()), 1) if len(rows) else 1), self.tokenizer.pad_id,
-                              dtype=np.int32)
-            for r, row in enumerate(rows):
-                all_ids[r, :len(row)] = row
         n = len(sentences)
-        order = np.argsort(all_lens, kind="stable")
         out = torch.empty((n, self.dim), dtype=torch.float16, device=self.device)
-        i = 0
-        while i < n:
-            j = i
-            # rows are sorted ascending, so the last row of a bucket sets its width
-            while j < n and (j - i + 1) * int(all_lens[order[j]]) <= max(batch_tokens, int(all_lens[order[j]])):
-                j += 1
-            idx = order[i:j]
-            T = int(all_lens[idx[-1]])
-            ids = np.ascontiguousarray(all_ids[idx, :T])
-            lens = np.ascontiguousarray(all_lens[idx])
-            out[torch.as_tensor(idx, device=self.device)] = self.encode_ids(ids, lens)
-            i = j
+        chunk_texts = 4096
+        for c0 in range(0, n, chunk_texts):
+            part = sentences[c0:c0 + chunk_texts]
+            if hasattr(self.tokenizer, "batch_native"):
+                all_ids, all_lens = self.tokenizer.batch_native(part, self.max_seq_length)
+            else:
+                rows = [self.tokenizer.encode(s, self.max_seq_length) for s in part]
+                all_lens = np.array([len(r) for r in rows], dtype=np.int32)
+                all_ids = np.full((len(rows), max(int(all_lens.max()), 1) if len(rows) else 1),
+                                  self.tokenizer.pad_id, dtype=np.int32)
+                for r, row in enumerate(rows):
+                    all_ids[r, :len(row)] = row
+            m = len(part)
+            if m * int(all_ids.shape[1]) <= self.SMALL_SLOTS:
+                # a query or a handful: straight to the small-batch path (no sorting, no side stream)
+                out[c0:c0 + m] = self.encode_ids(all_ids, all_lens)
+                continue
+            order = np.argsort(all_lens, kind="stable")
+            sorted_lens = all_lens[order].astype(np.int64)
+            # ONE upload per chunk, from pinned memory on a side stream: a pageable host-to-device copy
+            # on the compute stream would make the host wait for every kernel already queued there, and
+            # the chunk-to-chunk overlap would be gone.  Buckets are then gathered ON the device.
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            pin = [torch.from_numpy(a).pin_memory() for a in
+                   (np.ascontiguousarray(all_ids), all_lens, order.astype(np.int64))]
+            with torch.cuda.stream(self._copy_stream):
+                ids_dev, lens_dev, order_dev = (t.to(self.device, non_blocking=True) for t in pin)
+                ready = torch.cuda.Event()
+                ready.record()
+            torch.cuda.current_stream(self.device).wait_event(ready)
+            for t in (ids_dev, lens_dev, order_dev):
+                t.record_stream(torch.cuda.current_stream(self.device))
+            i = 0
+            while i < m:
+                # rows are sorted ascending, so the last row of a bucket sets its width and
+                # (rows in bucket) x (that width) is non-decreasing in the bucket's end: binary search
+                cost = (np.arange(1, m - i + 1, dtype=np.int64)) * sorted_lens[i:]
+                j = i + max(1, int(np.searchsorted(cost, batch_tokens, side="right")))
+                T = int(sorted_lens[j - 1])
+                sel = order_dev[i:j]
+                ids = ids_dev.index_select(0, sel)[:, :T].contiguous()
+                lens = lens_dev.index_select(0, sel)
+                out.index_copy_(0, sel + c0, self.encode_ids(ids, lens))
+                i = j
         return out
 
     def encode(self, sentences, batch_size: int = 32, **_ignored) -> np.ndarray:

@@ -104,6 +104,7 @@ class Embedder:
         self._ws = None
         self._small_lock = threading.Lock()
         self._copy_stream = None
+        self._pin = None
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -267,12 +268,29 @@ class Embedder:
             # the chunk-to-chunk overlap would be gone.  Buckets are then gathered ON the device.
             if self._copy_stream is None:
                 self._copy_stream = torch.cuda.Stream(device=self.device)
-            pin = [torch.from_numpy(a).pin_memory() for a in
-                   (np.ascontiguousarray(all_ids), all_lens, order.astype(np.int64))]
+            # two sets of pinned staging buffers used alternately, so that chunk k+1 can be staged
+            # while chunk k's copy is still in flight (allocating pinned memory per chunk would
+            # synchronise the device each time)
+            Tc = int(all_ids.shape[1])
+            if self._pin is None:
+                cap = chunk_texts * self.max_seq_length
+                self._pin = [dict(ids=torch.empty(cap, dtype=torch.int32).pin_memory(),
+                                  lens=torch.empty(chunk_texts, dtype=torch.int32).pin_memory(),
+                                  order=torch.empty(chunk_texts, dtype=torch.int64).pin_memory(),
+                                  done=None) for _ in range(2)]
+            pb = self._pin[(c0 // chunk_texts) & 1]
+            if pb["done"] is not None:
+                pb["done"].synchronize()      # its previous upload has left the buffers
+            pb["ids"][:m * Tc].view(m, Tc).copy_(torch.from_numpy(all_ids))
+            pb["lens"][:m].copy_(torch.from_numpy(all_lens))
+            pb["order"][:m].copy_(torch.from_numpy(order.astype(np.int64)))
             with torch.cuda.stream(self._copy_stream):
-                ids_dev, lens_dev, order_dev = (t.to(self.device, non_blocking=True) for t in pin)
+                ids_dev = pb["ids"][:m * Tc].view(m, Tc).to(self.device, non_blocking=True)
+                lens_dev = pb["lens"][:m].to(self.device, non_blocking=True)
+                order_dev = pb["order"][:m].to(self.device, non_blocking=True)
                 ready = torch.cuda.Event()
                 ready.record()
+            pb["done"] = ready
             torch.cuda.current_stream(self.device).wait_event(ready)
             for t in (ids_dev, lens_dev, order_dev):
                 t.record_stream(torch.cuda.current_stream(self.device))

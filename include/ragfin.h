@@ -191,7 +191,11 @@ int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cfg,
                       int device, void* stream);
 int rf_encoder_destroy(rf_encoder_t* enc);
 size_t rf_encode_workspace_bytes(const rf_encoder_t* enc, int B, int T);
-/* ids_dev int32 [B, T] (padded), lens_dev int32 [B] (valid tokens per row).
+/* Query-sized calls (B * T <= 1024): the launch sequence is captured once per (B, T, buffer
+ * pointers) into a hipGraph owned by the encoder handle and replayed on `stream` afterwards
+ * (RF_ENCODE_GRAPH=0 / rf_set_tuning("encode_graph", 0) keeps plain launches); callers that
+ * want the replay keep their buffers at fixed addresses (rag_fin_amd.embedder does).
+ * ids_dev int32 [B, T] (padded), lens_dev int32 [B] (valid tokens per row).
  * out_f16_dev fp16 [B, H] and/or out_f32_dev fp32 [B, H] (either nullable):
  * masked mean-pool + L2-normalise of the last hidden state. */
 int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev,

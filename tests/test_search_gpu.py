@@ -365,3 +365,24 @@ def test_tuning_variants_stay_exact(gpu_device):
     finally:
         for key, v in (("ring24", 8), ("emit_wgs_per_cu", 0), ("sample_bpw", 2), ("fused", 0), ("qreg", 0)):
             lib.rf_set_tuning(key.encode(), v)
+
+
+def test_search_host_downloads_once_and_resolves_flagged_queries(gpu_device):
+    """GpuIndex.search_host (the serving path's one-synchronisation download) on a corpus where
+    every row ties: all queries are flagged and must come back through the exhaustive kernel;
+    then on a plain corpus, twice with the same shape (cached pinned buffers)."""
+    import torch
+    row = osearch.synth_unit_rows(1, 384, 5)
+    c = np.repeat(row, 20_000, axis=0)
+    q16 = osearch.synth_unit_rows(3, 384, 6)
+    ix = make_index(c, gpu_device)
+    s, i = ix.search_host(torch.from_numpy(q16).to(gpu_device), 10)
+    os_, oi = c_oracle.search(q16, c, 10)
+    assert np.array_equal(i, oi) and np.array_equal(s, os_.astype(np.float32))
+    c2 = osearch.synth_unit_rows(30_000, 384, 7)
+    ix2 = make_index(c2, gpu_device)
+    for seed in (8, 9):
+        q2 = osearch.synth_unit_rows(5, 384, seed)
+        s2, i2 = ix2.search_host(torch.from_numpy(q2).to(gpu_device), 7)
+        os2, oi2 = c_oracle.search(q2, c2, 7)
+        assert np.array_equal(i2, oi2) and np.array_equal(s2, os2.astype(np.float32))

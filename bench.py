@@ -138,8 +138,12 @@ def main():
     if force_sharded:
         searcher.force_collective = True
     direct_rccl = False
-    if searcher is not None and os.environ.get("RAGFIN_DIRECT_RCCL", "1") == "1" and \
-            (force_sharded or os.environ.get("RAGFIN_DIST_BACKEND", "nccl") == "nccl"):
+    # (RAGFIN_DIRECT_RCCL=force tries it under the gloo rehearsal too: two ranks on ONE GPU make
+    # ncclCommInitRank fail with "duplicate GPU" AFTER the bootstrap exchange -- a check that the
+    # unique id really travels -- and the agreed fallback below takes over)
+    want_direct = os.environ.get("RAGFIN_DIRECT_RCCL", "1")
+    if searcher is not None and (want_direct == "force" or (want_direct == "1" and (
+            force_sharded or os.environ.get("RAGFIN_DIST_BACKEND", "nccl") == "nccl"))):
         # the step's all-gather straight through librccl (ctypes) on the lane's stream: torch's wrapper
         # costs ~25 us of host time per call, which bounds the strong-scaled job from 4 GPUs on
         try:

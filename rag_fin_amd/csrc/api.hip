@@ -137,6 +137,71 @@ static void fill_empty(int B, int k, float* scores, int64_t* ids, double* exact,
                      exact, flags);
 }
 
+int rf_tuning_generation = 0;
+// OFF by default (RF_SEARCH_GRAPH=1 / rf_set_tuning("search_graph", 1) to try it): measured no gain --
+// 20.7 vs 20.8 us/step on a 100 k-row corpus with 4 batches in flight, 40.2 vs 37.9 us on a 125 k-row
+// shard step: the step is bound by the dependent-kernel latency on the GPU, not by the host launches.
+int rf_tuning_search_graph = -1;
+
+static int search_enqueue(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_base, float* scores_dev,
+                          int64_t* ids_dev, double* exact_dev, uint32_t* flags_dev, void* workspace_dev,
+                          hipStream_t st);
+
+// Replay of a cached hipGraph for a call whose every buffer (and the corpus size, and the tuning
+// settings) is the one of an earlier call.  First call with a key: plain launches; second: capture
+// on a private stream + replay; later: replay.  RF_ERR_UNSUPPORTED = "use plain launches".
+static int search_graphed(const rf_index_t* ix, const void* q, int B, int k, int64_t id_base, float* scores,
+                          int64_t* ids, double* exact, uint32_t* flags, void* wsp, hipStream_t st) {
+  if (rf_tuning_search_graph < 0) {
+    const char* v = getenv("RF_SEARCH_GRAPH");
+    rf_tuning_search_graph = (v && v[0] == '1') ? 1 : 0;
+  }
+  if (!rf_tuning_search_graph || use_fused()) return RF_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(ix->graph_mu);
+  rf_index::Graph* g = nullptr;
+  for (auto& e : ix->graphs)
+    if (e.q == q && e.B == B && e.k == k && e.id_base == id_base && e.size == ix->size && e.scores == scores &&
+        e.ids == ids && e.exact == exact && e.flags == flags && e.ws == wsp && e.tuning_gen == rf_tuning_generation) {
+      g = &e;
+      break;
+    }
+  if (!g) {
+    if (ix->graphs.size() >= 32) {
+      if (ix->graphs.front().exec) (void)hipGraphExecDestroy(ix->graphs.front().exec);
+      ix->graphs.erase(ix->graphs.begin());
+    }
+    ix->graphs.push_back(rf_index::Graph{q, B, k, id_base, ix->size, scores, ids, exact, flags, wsp,
+                                         rf_tuning_generation, nullptr, false});
+    return RF_ERR_UNSUPPORTED;
+  }
+  if (g->dead) return RF_ERR_UNSUPPORTED;
+  if (!g->exec) {
+    if (!ix->cap_stream && hipStreamCreateWithFlags(&ix->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+      g->dead = true;
+      return RF_ERR_UNSUPPORTED;
+    }
+    if (hipStreamBeginCapture(ix->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      g->dead = true;
+      return RF_ERR_UNSUPPORTED;
+    }
+    const int rc = search_enqueue(ix, q, B, k, id_base, scores, ids, exact, flags, wsp, ix->cap_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t e1 = hipStreamEndCapture(ix->cap_stream, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (rc != RF_OK || e1 != hipSuccess || !graph ||
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      g->dead = true;
+      return RF_ERR_UNSUPPORTED;
+    }
+    (void)hipGraphDestroy(graph);
+    g->exec = exec;
+  }
+  RF_HIP(hipGraphLaunch(g->exec, st));
+  return RF_OK;
+}
+
 extern "C" int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_base,
                          float* scores_dev, int64_t* ids_dev, double* exact_dev,
                          uint32_t* flags_dev, void* workspace_dev, size_t workspace_bytes,
@@ -145,6 +210,17 @@ extern "C" int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, 
                              workspace_bytes);
   if (rc != RF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (ix->size > 0) {
+    rc = search_graphed(ix, q_dev, B, k, id_base, scores_dev, ids_dev, exact_dev, flags_dev, workspace_dev, st);
+    if (rc != RF_ERR_UNSUPPORTED) return rc;
+  }
+  return search_enqueue(ix, q_dev, B, k, id_base, scores_dev, ids_dev, exact_dev, flags_dev, workspace_dev, st);
+}
+
+static int search_enqueue(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_base, float* scores_dev,
+                          int64_t* ids_dev, double* exact_dev, uint32_t* flags_dev, void* workspace_dev,
+                          hipStream_t st) {
+  int rc = RF_OK;
   if (ix->size == 0) {
     fill_empty(B, k, scores_dev, ids_dev, exact_dev, flags_dev, st);
     RF_HIP(hipGetLastError());

@@ -97,7 +97,18 @@ extern "C" int rf_index_create(rf_index_t** out, int dim, int64_t capacity_rows,
   return RF_OK;
 }
 
+static void drop_graphs(rf_index* ix) {
+  std::lock_guard<std::mutex> lock(ix->graph_mu);
+  for (auto& g : ix->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  ix->graphs.clear();
+}
+
 extern "C" int rf_index_destroy(rf_index_t* ix) {
+  if (ix) {
+    drop_graphs(ix);
+    if (ix->cap_stream) (void)hipStreamDestroy(ix->cap_stream);
+  }
   delete ix;
   return RF_OK;
 }
@@ -212,6 +223,7 @@ extern "C" int rf_index_reset(rf_index_t* ix, void* stream) {
     rf_set_error("rf_index_reset: null index");
     return RF_ERR_INVALID;
   }
+  drop_graphs(ix);
   ix->size = 0;
   RF_HIP(hipMemsetAsync(ix->max_norm2, 0, 256, (hipStream_t)stream));
   return RF_OK;

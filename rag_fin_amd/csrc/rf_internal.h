@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
+#include <vector>
 #include "../../include/ragfin.h"
 
 // ---- tiled corpus layout ---------------------------------------------------
@@ -33,7 +35,23 @@ struct rf_index {
   int num_cus;         // compute units of `device` (sizes the co-resident fused grid)
   mutable const void* ws_clean[8];  // workspaces whose control block this index has zeroed
   mutable int ws_clean_next;
+  // rf_search calls that repeat with the same buffers (a serving lane, a shard's step) replay a
+  // cached hipGraph of their 4-5 launches: a launch costs ~4.5 us of host time, which -- not the
+  // kernels -- bounds the step on small corpora / shards
+  struct Graph {
+    const void* q;
+    int B, k;
+    int64_t id_base, size;
+    void *scores, *ids, *exact, *flags, *ws;
+    int tuning_gen;
+    hipGraphExec_t exec;   // nullptr: key seen once (that plain run also zeroes the workspace, sets attributes)
+    bool dead;
+  };
+  mutable std::vector<Graph> graphs;
+  mutable hipStream_t cap_stream = nullptr;
+  mutable std::mutex graph_mu;
 };
+extern int rf_tuning_generation;   // bumped by rf_set_tuning: cached graphs of older settings are not replayed
 
 // queries per wide sweep (scan_wide.hip); every per-query workspace array is sized for it
 #define RF_QWIDE 256

@@ -339,9 +339,15 @@ static ScanTuning& tuning() {
                          env_int("RF_SAMPLE_BPW", 2), env_int("RF_QREG", 0)};
   return t;
 }
+extern int rf_tuning_search_graph;   // api.hip
 extern "C" int rf_set_tuning(const char* key, int value) {
   ScanTuning& t = tuning();
   if (!key) return RF_ERR_INVALID;
+  ++rf_tuning_generation;   // cached search graphs were captured under the old settings
+  if (!strcmp(key, "search_graph") && (value == 0 || value == 1)) {
+    rf_tuning_search_graph = value;
+    return RF_OK;
+  }
   if (!strcmp(key, "ring24") && (value == 6 || value == 8 || value == 12 || value == 24)) t.ring24 = value;
   else if (!strcmp(key, "emit_wgs_per_cu") && value >= 0 && value <= 4) t.emit_wgs_per_cu = value;
   else if (!strcmp(key, "sample_bpw") && value >= 1 && value <= 8) t.sample_bpw = value;

@@ -386,3 +386,36 @@ def test_search_host_downloads_once_and_resolves_flagged_queries(gpu_device):
         s2, i2 = ix2.search_host(torch.from_numpy(q2).to(gpu_device), 7)
         os2, oi2 = c_oracle.search(q2, c2, 7)
         assert np.array_equal(i2, oi2) and np.array_equal(s2, os2.astype(np.float32))
+
+
+def test_search_graph_replay_is_exact(gpu_device):
+    """rf_set_tuning("search_graph", 1): a call that repeats with the same buffers is captured
+    into a hipGraph on its second occurrence and replayed afterwards -- results stay bit-exact,
+    including after the query CONTENTS change in place and after the corpus grows (new key)."""
+    import torch
+    from rag_fin_amd import _lib
+    lib = _lib.load_library()
+    c = osearch.synth_unit_rows(50_000, 384, 71)
+    ix = make_index(c[:40_000], gpu_device, capacity=50_000)
+    q = torch.empty((64, 384), dtype=torch.float16, device=gpu_device)
+    out = (torch.empty((64, 10), dtype=torch.float32, device=gpu_device),
+           torch.empty((64, 10), dtype=torch.int64, device=gpu_device),
+           torch.empty((64, 10), dtype=torch.float64, device=gpu_device),
+           torch.empty((64,), dtype=torch.int32, device=gpu_device))
+    try:
+        _lib.check(lib.rf_set_tuning(b"search_graph", 1))
+        n = 40_000
+        for rnd in range(6):
+            if rnd == 4:                                   # corpus grows: the cached graph must not be replayed
+                ix.add(torch.from_numpy(c[40_000:]).to(gpu_device))
+                n = 50_000
+            q16 = osearch.synth_unit_rows(64, 384, 80 + rnd)
+            q.copy_(torch.from_numpy(q16).to(gpu_device))
+            ix.search_raw(q, 10, want_exact=True, out=out)
+            torch.cuda.synchronize()
+            os_, oi = c_oracle.search(q16, c[:n], 10)
+            assert int(out[3].abs().sum()) == 0
+            assert np.array_equal(out[1].cpu().numpy(), oi), rnd
+            assert np.array_equal(out[2].cpu().numpy(), os_), rnd
+    finally:
+        lib.rf_set_tuning(b"search_graph", 0)

@@ -187,6 +187,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup, not warm-up: first use of every lane (code objects, kernel attributes, the one-time
+    # zeroing of each workspace's control block, RCCL's first collective) happens here, so that
+    # short runs (--steps 5 --warmup 1) time steady-state steps too
+    for l in lanes:
+        with torch.cuda.stream(l["stream"]):
+            for _ in range(2):
+                if searcher is not None:
+                    searcher.search(q, k, workspace=l["ws"])
+                else:
+                    index.search_raw(q, k, want_exact=True, out=l["out"], workspace=l["ws"])
+    barrier()
+
     def timed_region(n_lanes):
         """W untimed + exactly K timed steps, barrier + synchronize on both sides."""
         counter = [0]

@@ -915,7 +915,11 @@ __global__ void __launch_bounds__(256, 2) k_attention_mfma(const _Float16* __res
           for (int i = 0; i < 16; ++i)
             if (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= n) acc[i] = -INFINITY;
         }
-        // running maximum by v_max3_f32 (two new elements per instruction)
+        // running maximum by v_max3_f32 (two new elements per instruction).  att_max3 is inline
+        // asm, which hipcc's hazard recognizer does not see reading the MFMA result: the wait
+        // states an XDL write needs before a VALU read (11 for the 8-pass 32x32x16) are supplied
+        // by hand, as nops that take the accumulator as an in/out operand.
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
 #pragma unroll
         for (int i = 0; i < 16; i += 2) m = att_max3(m, acc[i], acc[i + 1]);
         sc[kb] = acc;

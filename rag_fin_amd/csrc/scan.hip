@@ -360,7 +360,7 @@ extern "C" int rf_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "linear_dbg") && value >= 0 && value <= 15) rf_debug_linear_flags = value;
   else if (!strcmp(key, "debug_epi") && (value == 0 || value == 1)) rf_debug_epi = value;
   else if (!strcmp(key, "fused") && (value == 0 || value == 1)) rf_tuning_fused = value;
-  else if (!strcmp(key, "wide_variant") && value >= 0 && value <= 2) rf_tuning_wide_variant = value;
+  else if (!strcmp(key, "wide_variant") && value >= 0 && value <= 3) rf_tuning_wide_variant = value;
   else if (!strcmp(key, "wide_nt") && (value == 0 || value == 1)) rf_tuning_wide_nt = value;
   else if (!strcmp(key, "wide_sample_pairs") && value >= 1 && value <= 8) rf_tuning_wide_sample_pairs = value;
   else if (!strcmp(key, "wide_dbg") && value >= 0 && value <= 63) rf_tuning_wide_dbg = value;

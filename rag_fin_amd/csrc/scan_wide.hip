@@ -274,7 +274,14 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-__device__ __forceinline__ float max16_v3(const f32x16& a) {
+__device__ __forceinline__ float max16_v3(const f32x16& a_in) {
+  // The v_max3 below are inline asm: hipcc's hazard recognizer does not see them read MFMA
+  // results, so the wait states an XDL write needs before a VALU read (11 for the 8-pass
+  // 32x32x16) must be supplied by hand when the accumulator lives in arch VGPRs (with AGPR
+  // accumulators the compiler's own v_accvgpr_read carried them).  The nops take the
+  // accumulator as an in/out operand, which orders them after the MFMA and before the reads.
+  f32x16 a = a_in;
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a));
   float m = vmax3(a[0], a[1], a[2]);
   m = vmax3(m, a[3], a[4]);
   m = vmax3(m, a[5], a[6]);
@@ -287,9 +294,13 @@ __device__ __forceinline__ float max16_v3(const f32x16& a) {
 
 // ABL: compile-time ablation of the diagnostic builds (tools/bench_wide.py --dbg 8|16|32, results
 // are then wrong): 1 = no LDS-DMA in the loop, 2 = no filters, 4 = no LDS fragment reads
-template <int MODE, int AUX, int NW, int ABL = 0>
+template <int MODE, int AUX, int NW, int ABL = 0, int PIN = 0>
 __global__ void __launch_bounds__(NW * 64, 1) k_scan_ldsdma(WideParams p) {
   constexpr int JBW = RF_QWIDE / 32 / NW;        // query blocks per wave: 2 | 1
+  // NW = 4 must park its 192 query registers in the accumulator half; NW = 8 (96 of them, 256
+  // registers per wave) may keep EVERYTHING in arch VGPRs, and then the MFMA results need no
+  // v_accvgpr_read before the filter's v_max3 (PIN = 1 pins for NW = 8 too: wide_variant 3, the A/B arm)
+  constexpr bool PIN_Q = (NW == 4) || PIN;
   constexpr int PW = WL_FRAGS / NW;              // LDS-DMA pieces per wave and phase: 12 | 6
   constexpr int CAP = WL_STAGE_WORDS / 3 / NW;   // emit staging entries per wave: 256 | 128
   static_assert(JBW * 32 * NW == RF_QWIDE && PW * NW == WL_FRAGS && WIDE_KS % PW == 0, "tiling");
@@ -373,7 +384,8 @@ __global__ void __launch_bounds__(NW * 64, 1) k_scan_ldsdma(WideParams p) {
     for (int kk = 0; kk < WIDE_KS; ++kk) {
       u32x4 v = qf[jb][kk];
       if (qi >= p.B) v = u32x4{0u, 0u, 0u, 0u};
-      asm volatile("" : "+a"(v));
+      if (PIN_Q) asm volatile("" : "+a"(v));
+      else asm volatile("" : "+v"(v));
       qf[jb][kk] = v;
     }
   }
@@ -503,14 +515,15 @@ __global__ void __launch_bounds__(NW * 64, 1) k_scan_ldsdma(WideParams p) {
 }
 
 // ---- host side of the LDS-DMA form ----------------------------------------------------------
-int rf_tuning_wide_variant = -1;   // 0 = register-staged form, 1 = LDS-DMA 4 waves, 2 = LDS-DMA 8 waves
+int rf_tuning_wide_variant = -1;   // 0 = register-staged form, 1 = LDS-DMA 4 waves, 2 = LDS-DMA 8 waves (all in arch
+                                   // VGPRs), 3 = LDS-DMA 8 waves with the queries pinned to the accumulator half
 int rf_tuning_wide_nt = -1;        // LDS-DMA cache policy: 0 default, 1 non-temporal (aux = 2)
 int rf_tuning_wide_dbg = 0;        // ablation bits (WideParams::dbg)
 int rf_tuning_wide_sample_pairs = 4;   // sample pass: block pairs (phases) per workgroup, at most
 static int wide_variant() {
   if (rf_tuning_wide_variant < 0) {
     const char* v = getenv("RF_WIDE_VARIANT");
-    rf_tuning_wide_variant = (v && v[0] >= '0' && v[0] <= '2') ? v[0] - '0' : 2;
+    rf_tuning_wide_variant = (v && v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 2;
   }
   return rf_tuning_wide_variant;
 }
@@ -522,11 +535,11 @@ static int wide_nt() {
   return rf_tuning_wide_nt;
 }
 
-template <int MODE, int AUX, int NW, int ABL = 0>
+template <int MODE, int AUX, int NW, int ABL = 0, int PIN = 0>
 static int launch_ldsdma(const WideParams& p, int grid, hipStream_t st) {
   const size_t lds = (size_t)WL_SLOTS * WL_FRAGS * RF_FRAG_BYTES + (size_t)WL_STAGE_WORDS * 4 +
                      (size_t)RF_FRAG_BYTES;   // slots, emit staging, dump area
-  auto kern = k_scan_ldsdma<MODE, AUX, NW, ABL>;
+  auto kern = k_scan_ldsdma<MODE, AUX, NW, ABL, PIN>;
   static bool attr_done = false;
   if (!attr_done) {
     RF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -538,7 +551,7 @@ static int launch_ldsdma(const WideParams& p, int grid, hipStream_t st) {
 }
 template <int MODE>
 static int dispatch_ldsdma(const WideParams& p, int grid, hipStream_t st) {
-  const bool w8 = wide_variant() == 2;
+  const bool w8 = wide_variant() >= 2;
   if (MODE == MODE_EMIT) {
     switch (rf_tuning_wide_dbg >> 3) {   // diagnostic builds (non-temporal, current wave count)
 #define WL_ABL(x) case x: return w8 ? launch_ldsdma<MODE_EMIT, 2, 8, x>(p, grid, st) : launch_ldsdma<MODE_EMIT, 2, 4, x>(p, grid, st);
@@ -547,6 +560,8 @@ static int dispatch_ldsdma(const WideParams& p, int grid, hipStream_t st) {
       default: break;
     }
   }
+  if (wide_variant() == 3)   // 8 waves with the queries pinned to the accumulator half (the first LDS-DMA form)
+    return launch_ldsdma<MODE, 2, 8, 0, 1>(p, grid, st);
   if (wide_nt())
     return w8 ? launch_ldsdma<MODE, 2, 8>(p, grid, st) : launch_ldsdma<MODE, 2, 4>(p, grid, st);
   return w8 ? launch_ldsdma<MODE, 0, 8>(p, grid, st) : launch_ldsdma<MODE, 0, 4>(p, grid, st);

@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--variants", default="2:1,1:1,0:1",
-                    help="wide_variant:wide_nt pairs (0 register-staged, 1 LDS-DMA 4 waves, 2 LDS-DMA 8 waves)")
+                    help="wide_variant:wide_nt pairs (0 register-staged, 1 LDS-DMA 4 waves, 2 LDS-DMA 8 waves, 3 = 2 with AGPR-pinned queries)")
     ap.add_argument("--sample-pairs", type=int, default=4)
     ap.add_argument("--dbg", type=int, default=0, help="ablation bits of the 4-wave kernel (results are then wrong)")
     ap.add_argument("--check", action="store_true", help="compare ids of every variant with variant 0")
@@ -73,7 +73,7 @@ def main():
     if args.dbg & 4:
         # clock stamps of the last launch: [workgroup][wave] x {cycles, 100-MHz ticks, wait cycles, phases}
         off = lib.rf_debug_workspace_offset(b"pmax")
-        nw = 8 if variants[-1][0] == 2 else 4
+        nw = 8 if variants[-1][0] >= 2 else 4
         st = ix.workspace[off:off + 256 * nw * 4 * 4].view(torch.float32).view(256, nw, 4).cpu().numpy()
         cyc, ticks, wait, ph = st[..., 0], st[..., 1], st[..., 2], st[..., 3]
         ok = ticks > 0

@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=4,
-                    help="batches in flight (one HIP stream + workspace each); 1 = strictly serial steps")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="batches in flight (one HIP stream + workspace each); 1 = strictly serial steps; "
+                         "0 = 4 on one GPU, 8 for the sharded step (its scan is short: 31.9 vs 37.5 us/step at 125 k-row shards)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--group", action="store_true",
@@ -100,6 +101,8 @@ def main():
     # RAGFIN_FORCE_SHARDED=1 at N=1: run the N>1 code path (scan -> RCCL all-gather -> merge) with
     # a one-rank communicator, to measure its per-step overhead on a single-GPU box
     force_sharded = world == 1 and os.environ.get("RAGFIN_FORCE_SHARDED") == "1"
+    if args.streams <= 0:
+        args.streams = 8 if (world > 1 or force_sharded) else 4
     if force_sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
@@ -325,12 +328,35 @@ def main():
             for _ in range(n2):
                 r2 = index.search_raw(q2, k, want_exact=True)
             torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t0) / n2
+            dt2_serial = (time.perf_counter() - t0) / n2
+            # two batches in flight (two of the lanes above: own stream, workspace and outputs):
+            # threshold and merge of one batch run beside the other's sweep
+            from ctypes import c_void_p as _vp
+            lanes2 = []
+            for l in lanes[:int(os.environ.get("RAGFIN_B256_LANES", "2"))]:
+                o = (torch.empty((B2, k), dtype=torch.float32, device=dev), torch.empty((B2, k), dtype=torch.int64, device=dev),
+                     torch.empty((B2, k), dtype=torch.float64, device=dev), torch.empty((B2,), dtype=torch.int32, device=dev))
+                lanes2.append((o, (q2.data_ptr(), B2, k, 0, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                                   o[3].data_ptr(), l["ws"].data_ptr(), _vp(l["stream"].cuda_stream))))
+            dt2 = dt2_serial
+            if len(lanes2) >= 2:
+                for i in range(6):
+                    index.enqueue_search(*lanes2[i % len(lanes2)][1])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n2):
+                    index.enqueue_search(*lanes2[i % len(lanes2)][1])
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t0) / n2
+                same = all(bool((a == b).all().item()) for a, b in zip(lanes2[(n2 - 1) % len(lanes2)][0], r2))
+                if not same:
+                    raise SystemExit("bench: batch-256 result with two batches in flight differs from the serial one")
             flops2 = 2.0 * B2 * rows * dim
             result["batch256"] = {
                 "workload": "%s x %d-d fp16 corpus, batch-256 queries, top-%d (configs[2])" % (f"{rows:,}", dim, k),
                 "value": round(B2 / dt2, 1), "unit": "queries/s", "ms_per_step": round(dt2 * 1e3, 5),
-                "steps": n2, "flags_clean": int(r2[3].abs().sum().item()) == 0,
+                "steps": n2, "batches_in_flight": len(lanes2), "serial_ms_per_step": round(dt2_serial * 1e3, 5),
+                "flags_clean": int(r2[3].abs().sum().item()) == 0,
                 "whole_step_GBps": round(alg_bytes / dt2 / 1e9, 1),
                 "hbm_frac": round(alg_bytes / dt2 / 1e9 / HBM_PEAK_GBPS, 4),
                 "whole_step_TFLOPs": round(flops2 / dt2 / 1e12, 1),

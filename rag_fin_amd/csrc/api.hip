@@ -302,6 +302,10 @@ extern "C" int rf_search_profile(const rf_index_t* ix, const void* q_dev, int B,
     rc = rf_launch_sample(ix, q_dev, nb, JB, ws, &P, st);
   RF_HIP(hipEventRecord(ev[1], st));
   if (rc == RF_OK && !use_fused()) rc = rf_launch_threshold(ix, q_dev, nb, k, P, ws, st);
+  // RF_DEBUG_NO_HITS=1 (timing experiments only, results wrong): thresholds of 3.4e38, so the
+  // emit sweep appends nothing -- what the candidate path costs is the difference
+  static const bool no_hits = getenv("RF_DEBUG_NO_HITS") != nullptr;
+  if (no_hits) RF_HIP(hipMemsetAsync(ws.thr, 0x7f, RF_QCHUNK * sizeof(float), st));
   RF_HIP(hipEventRecord(ev[2], st));
   if (rc == RF_OK)
     rc = use_fused() ? rf_launch_fused(ix, q_dev, nb, JB, k, ws, st) : rf_launch_emit(ix, q_dev, nb, JB, ws, st);

@@ -362,6 +362,40 @@ def main():
                 "whole_step_TFLOPs": round(flops2 / dt2 / 1e12, 1),
                 "mfma_frac_of_2500_dense_f16": round(flops2 / dt2 / 1e12 / 2500.0, 4)}
 
+        # ---- the same step for a caller that hands over HOST buffers (not `value`: reported beside
+        # it): queries come from pinned host memory and scores + ids go back to pinned host memory,
+        # on the lane's stream, four batches in flight
+        if world == 1 and searcher is None:
+            hl = []
+            for l in lanes:
+                o = l["out"]
+                hl.append(dict(stream=l["stream"], ws=l["ws"], out=o, q_dev=torch.empty_like(q),
+                               q_host=q.cpu().pin_memory(), s_host=torch.empty((B, k), dtype=torch.float32).pin_memory(),
+                               i_host=torch.empty((B, k), dtype=torch.int64).pin_memory()))
+
+            def host_step(i):
+                l = hl[i % len(hl)]
+                with torch.cuda.stream(l["stream"]):
+                    l["q_dev"].copy_(l["q_host"], non_blocking=True)
+                    index.search_raw(l["q_dev"], k, want_exact=True, out=l["out"], workspace=l["ws"])
+                    l["s_host"].copy_(l["out"][0], non_blocking=True)
+                    l["i_host"].copy_(l["out"][1], non_blocking=True)
+            for i in range(2 * len(hl)):
+                host_step(i)
+            torch.cuda.synchronize()
+            nh = max(20, args.steps // 2)
+            t0 = time.perf_counter()
+            for i in range(nh):
+                host_step(i)
+            torch.cuda.synchronize()
+            dth = (time.perf_counter() - t0) / nh
+            result["pcie_inclusive"] = {
+                "value": round(B / dth, 1), "unit": "queries/s", "ms_per_step": round(dth * 1e3, 5), "steps": nh,
+                "batches_in_flight": len(hl),
+                "what": "pinned-host queries in (%d B), scores + ids out to pinned host (%d B) per step" % (
+                    B * dim * 2, B * k * 12),
+                "ids_match_device_path": bool((hl[(nh - 1) % len(hl)]["i_host"] == out[1].cpu()).all().item())}
+
         # ---- correctness beside the number: recall@10 / exact ids vs the CPU oracle
         if not args.no_check:
             from oracle import c_oracle

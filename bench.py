@@ -81,6 +81,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # read by the HSA runtime when the first HIP call initialises it: must be set before torch
+    # touches the GPU (the host driver only supports dmabuf IPC, which RCCL needs across processes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -271,6 +274,25 @@ def main():
         flags_clean = all(int(r[2].abs().sum().item()) == 0 for r in done) and \
             all(torch.equal(r[1], done[0][1]) for r in done)
 
+    # N > 1: the merged (global) answer is checked against the oracle too -- every rank runs the
+    # C oracle on ITS shard for the first queries, the per-shard oracle lists are all-gathered and
+    # rank 0 merges them by (score desc, id asc): what an oracle over the whole corpus would return
+    global_oracle = None
+    if world > 1 and searcher is not None and not args.no_check:
+        from oracle import c_oracle
+        nq = min(8, B)
+        os_l, oi_l = c_oracle.search(q16[:nq], c16, k)
+        on_gpu = dist.get_backend() == "nccl"
+        cdev = dev if on_gpu else torch.device("cpu")
+        t_s = torch.from_numpy(np.ascontiguousarray(os_l, dtype=np.float64)).to(cdev)
+        t_i = torch.from_numpy(np.ascontiguousarray(oi_l, dtype=np.int64) + row_base).to(cdev)
+        # concatenated form [world * nq, k] (the one every backend takes), viewed as [world, nq, k]
+        all_s = torch.empty((world * nq, k), dtype=torch.float64, device=cdev)
+        all_i = torch.empty((world * nq, k), dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(all_s, t_s.contiguous())
+        dist.all_gather_into_tensor(all_i, t_i.contiguous())
+        global_oracle = (all_s.cpu().numpy().reshape(world, nq, k), all_i.cpu().numpy().reshape(world, nq, k))
+
     result = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -412,6 +434,19 @@ def main():
             result["ids_ranks_exact"] = bool(np.array_equal(gi, oi))
             result["max_abs_score_err"] = float(np.abs(ge - os_).max())
             result["checked_queries"] = nq
+            if global_oracle is not None and res is not None:
+                gs, gid = global_oracle   # [world, nq, k]
+                exp_i = np.empty((nq, k), dtype=np.int64)
+                exp_s = np.empty((nq, k), dtype=np.float64)
+                for b in range(nq):
+                    cs, ci = gs[:, b, :].reshape(-1), gid[:, b, :].reshape(-1)
+                    order = np.lexsort((ci, -cs))[:k]
+                    exp_i[b], exp_s[b] = ci[order], cs[order]
+                got_i = res[1][:nq].cpu().numpy()
+                got_s = res[0][:nq].cpu().numpy().astype(np.float64)
+                result["global_ids_ranks_exact"] = bool(np.array_equal(got_i, exp_i))
+                result["global_recall_at_10"] = float(np.mean([len(set(got_i[b]) & set(exp_i[b])) / k for b in range(nq)]))
+                result["global_max_abs_score_err"] = float(np.abs(got_s - exp_s).max())
 
         # ---- CPU baseline leg (rank 0, N=1 only): the oracle's BLAS restatement of the
         # reference's search semantics on the host cores, same data

@@ -60,6 +60,7 @@ struct rf_encoder {
     int B, T;
     const void *ids, *lens;
     void *o16, *o32, *ws;
+    int tuning_gen;        // rf_set_tuning generation the graph was captured under
     hipGraphExec_t exec;   // nullptr: seen once (the plain run also sets the kernels' attributes)
     bool dead;             // capture failed for this key: stay on plain launches
   };
@@ -158,6 +159,7 @@ struct EncWs {
   _Float16* ctx;      // [Mpad, 384]
   _Float16* ff;       // [Mpad, I]
   float* pre;         // [min(Mpad, SM_MAX_TOK), 384] fp32: pre-LayerNorm sums of the small-batch path
+  uint32_t* ln_ctr;   // [SM_MAX_TOK / 64] arrival counters of the small-batch LayerNorm hand-off (zeroed by k_tok_offsets)
 };
 
 static size_t enc_carve(unsigned char* base, int B, int T, int I, EncWs* ws) {
@@ -175,7 +177,8 @@ static size_t enc_carve(unsigned char* base, int B, int T, int I, EncWs* ws) {
   _Float16* ctx = (_Float16*)take(Mpad * HID * 2);
   _Float16* ff = (_Float16*)take(Mpad * (size_t)I * 2);
   float* pre = (float*)take((Mpad < SM_MAX_TOK ? Mpad : (size_t)SM_MAX_TOK) * HID * 4);
-  if (ws) *ws = EncWs{tok, x, y, qkv, ctx, ff, pre};
+  uint32_t* ln_ctr = (uint32_t*)take((SM_MAX_TOK / 64) * 4);
+  if (ws) *ws = EncWs{tok, x, y, qkv, ctx, ff, pre, ln_ctr};
   return off;
 }
 
@@ -191,7 +194,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __global__ void __launch_bounds__(256) k_tok_offsets(const int32_t* __restrict__ lens, int B, int T,
-                                                     int32_t* __restrict__ tok_off) {
+                                                     int32_t* __restrict__ tok_off, uint32_t* __restrict__ ln_ctr) {
+  if (threadIdx.x < SM_MAX_TOK / 64) ln_ctr[threadIdx.x] = 0u;   // first kernel of every forward
   // exclusive scan of clamp(lens, 0, T) by one workgroup
   __shared__ int32_t part[256];
   const int tid = threadIdx.x;
@@ -690,6 +694,40 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
   }
 }
 
+// LayerNorm of ONE fp32 row [384] -> fp16 tiled activations, by one wave
+__device__ __forceinline__ void ln_row(const float* __restrict__ pre, int token, int lane,
+                                       const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
+                                       float eps, _Float16* __restrict__ out) {
+  // lane l < 48 owns features 8 l .. 8 l + 7
+  float v[8];
+  if (lane < 48) {
+    const float4 a = *(const float4*)(pre + (size_t)token * HID + lane * 8);
+    const float4 b = *(const float4*)(pre + (size_t)token * HID + lane * 8 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += v[j];
+  const float mu = wave_sum(s) * (1.f / HID);
+  float q = 0.f;
+  if (lane < 48) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q += (v[j] - mu) * (v[j] - mu);
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.f / HID) + eps);
+  if (lane < 48) {
+    const half8 gg = *(const half8*)(gamma + lane * 8);
+    const half8 bb = *(const half8*)(beta + lane * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)((v[j] - mu) * rstd * (float)gg[j] + (float)bb[j]);
+    *(half8*)(out + toff(token, lane * 8, HID / 16)) = o;
+  }
+}
+
 // ---- small batches (a single query: the reference's only serving mode) -------------------
 // With a handful of tokens the GEMMs above are latency chains: one 64/128-token tile means one
 // workgroup per 384 (or all N) features streaming 0.3-1.2 MB of weights through ONE CU --
@@ -706,7 +744,8 @@ template <int EPI, int KS>
 __global__ void __launch_bounds__(256) k_linear_small(
     const _Float16* __restrict__ X, const uint4* __restrict__ Wt, const _Float16* __restrict__ bias,
     _Float16* __restrict__ out, float* __restrict__ pre, int N, const int32_t* __restrict__ m_ptr,
-    const _Float16* __restrict__ res) {
+    const _Float16* __restrict__ res, const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
+    float eps, uint32_t* __restrict__ ln_ctr) {
   constexpr int KW = KS / 4;   // k-steps per wave
   __shared__ float red[4][2][16][64];   // [wave][token block][register][lane]: 32 KB
   const int tid = threadIdx.x;
@@ -789,44 +828,40 @@ __global__ void __launch_bounds__(256) k_linear_small(
       if (token < M) *(half4*)(out + toff(token, f, N / 16)) = o;
     }
   }
+  // LayerNorm tail (ln_ctr != nullptr; rf_set_tuning("ln_tail", 1), OFF by default -- measured slower,
+  // see rf_tuning_ln_tail): the workgroup whose fp32 sums complete a 64-token block -- the last of the
+  // N / 32 feature blocks to arrive at that block's counter -- normalises its rows, so the LayerNorm
+  // needs no launch of its own (12 of the 45 launches of a forward).  Hand-off: every thread's stores, an agent-scope
+  // fence, the workgroup barrier, ONE atomic add by thread 0; the workgroup that drew the last ticket
+  // fences again (acquire: the other workgroups' rows may sit in another XCD's L2) and reads.
+  // Same arithmetic as k_ln_rows on the same fp32 sums: bit-identical output.
+  if (EPI == EPI_PRE_LN && ln_ctr != nullptr) {
+    __shared__ uint32_t s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t t = __hip_atomic_fetch_add(&ln_ctr[blockIdx.y], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == gridDim.x - 1u) ? 1u : 0u;
+      if (s_last) __hip_atomic_store(&ln_ctr[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next GEMM
+    }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      const int end = (t0 + SM_TOK < M) ? t0 + SM_TOK : M;
+      for (int tk = t0 + wave; tk < end; tk += 4) ln_row(pre, tk, lane, gamma, beta, eps, out);
+    }
+  }
 }
 
 // LayerNorm of fp32 rows [token][384] -> fp16 tiled activations; one wave per token
+// (rf_set_tuning("ln_tail", 0): the separate-launch form of the small-batch LayerNorm)
 __global__ void __launch_bounds__(256) k_ln_rows(const float* __restrict__ pre, const int32_t* __restrict__ m_ptr,
                                                  const _Float16* __restrict__ gamma,
                                                  const _Float16* __restrict__ beta, float eps,
                                                  _Float16* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
   const int token = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (token >= *m_ptr) return;
-  // lane l < 48 owns features 8 l .. 8 l + 7
-  float v[8];
-  if (lane < 48) {
-    const float4 a = *(const float4*)(pre + (size_t)token * HID + lane * 8);
-    const float4 b = *(const float4*)(pre + (size_t)token * HID + lane * 8 + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = 0.f;
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) s += v[j];
-  const float mu = wave_sum(s) * (1.f / HID);
-  float q = 0.f;
-  if (lane < 48) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q += (v[j] - mu) * (v[j] - mu);
-  }
-  const float rstd = rsqrtf(wave_sum(q) * (1.f / HID) + eps);
-  if (lane < 48) {
-    const half8 gg = *(const half8*)(gamma + lane * 8);
-    const half8 bb = *(const half8*)(beta + lane * 8);
-    half8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (_Float16)((v[j] - mu) * rstd * (float)gg[j] + (float)bb[j]);
-    *(half8*)(out + toff(token, lane * 8, HID / 16)) = o;
-  }
+  ln_row(pre, token, threadIdx.x & 63, gamma, beta, eps, out);
 }
 
 // Attention on the matrix cores for sequences of <= 256 tokens (the model's
@@ -1099,6 +1134,10 @@ int rf_tuning_ffn2_ntb = 4;   // token blocks per workgroup of the K = 1536 Laye
                               // halve the weight traffic per token (22.4 vs 21.7 M tokens/s)
 int rf_tuning_k384_ntb = 4;   // the same for the K = 384 direct-load GEMM that is left at large batch (out-proj + LN: +1 %;
                               // for QKV / FFN1 with linear_dma = 0 the 64-token tiles are faster: 21.1 vs 19.8 M tokens/s)
+int rf_tuning_ln_tail = 0;        // small-batch path: 1 = LayerNorm by the last-arriving workgroup of the GEMM instead of
+                                  // its own launch.  Measured SLOWER (a 12-token query: encode 250 vs 222 us, same box,
+                                  // bit-identical output): the hand-off's two agent-scope fences and the atomic round trip
+                                  // cost more than the ~5 us of a dependent launch they remove.  Kept as an A/B knob.
 int rf_tuning_linear_small = 1;   // B * T <= SM_MAX_TOK: feature-split GEMMs + separate LayerNorm (A/B knob)
 int rf_tuning_linear_dma = 1;   // K = 384 GEMMs with plain epilogues through the LDS-DMA ring (A/B knob)
 
@@ -1108,18 +1147,19 @@ int rf_tuning_linear_dma = 1;   // K = 384 GEMMs with plain epilogues through th
 template <int EPI>
 static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Float16* bias,
                           _Float16* out, int N, int tokens, const int32_t* m_ptr, const _Float16* res,
-                          const _Float16* g, const _Float16* b, float eps, float* pre, hipStream_t st) {
+                          const _Float16* g, const _Float16* b, float eps, float* pre, uint32_t* ln_ctr, hipStream_t st) {
   constexpr int NTB = 2;
   const int tiles = (tokens + 32 * NTB - 1) / (32 * NTB);
   if (tokens <= SM_MAX_TOK && rf_tuning_linear_small) {
     // small batches: output features spread over the chip (k_linear_small), LayerNorm as its own launch
     const dim3 grid(N / 32, (tokens + SM_TOK - 1) / SM_TOK);
     constexpr int E = (EPI == EPI_BIAS_RES_LN) ? (int)EPI_PRE_LN : (int)EPI;
+    uint32_t* ctr = (EPI == EPI_BIAS_RES_LN && rf_tuning_ln_tail) ? ln_ctr : nullptr;
     if (K == 384)
-      hipLaunchKernelGGL((k_linear_small<E, 24>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res);
+      hipLaunchKernelGGL((k_linear_small<E, 24>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res, g, b, eps, ctr);
     else
-      hipLaunchKernelGGL((k_linear_small<E, 96>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res);
-    if (EPI == EPI_BIAS_RES_LN)
+      hipLaunchKernelGGL((k_linear_small<E, 96>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res, g, b, eps, ctr);
+    if (EPI == EPI_BIAS_RES_LN && !ctr)
       hipLaunchKernelGGL(k_ln_rows, dim3((tokens + 3) / 4), dim3(256), 0, st, pre, m_ptr, g, b, eps, out);
     return;
   }
@@ -1165,6 +1205,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
 // First call with a (shape, buffers) key: plain launches.  Second: the same launch sequence is
 // captured on a private stream, instantiated and replayed on the caller's stream; later calls
 // replay.  Returns RF_ERR_UNSUPPORTED when the caller should use plain launches.
+extern int rf_tuning_generation;   // api.hip: bumped by every rf_set_tuning
 static int encode_graphed(const rf_encoder_t* enc, const int32_t* ids, const int32_t* lens, int B, int T, void* o16,
                           float* o32, void* wsp, hipStream_t st) {
   if (rf_tuning_encode_graph < 0) {
@@ -1173,6 +1214,15 @@ static int encode_graphed(const rf_encoder_t* enc, const int32_t* ids, const int
     if (!rf_tuning_encode_graph) return RF_ERR_UNSUPPORTED;
   }
   std::lock_guard<std::mutex> lock(enc->mu);
+  // graphs captured under other tuning settings (rf_set_tuning picks kernels) are dropped
+  for (size_t i = 0; i < enc->graphs.size();) {
+    if (enc->graphs[i].tuning_gen != rf_tuning_generation) {
+      if (enc->graphs[i].exec) (void)hipGraphExecDestroy(enc->graphs[i].exec);
+      enc->graphs.erase(enc->graphs.begin() + i);
+    } else {
+      ++i;
+    }
+  }
   rf_encoder::Graph* g = nullptr;
   for (auto& e : enc->graphs)
     if (e.B == B && e.T == T && e.ids == ids && e.lens == lens && e.o16 == o16 && e.o32 == (void*)o32 && e.ws == wsp) {
@@ -1184,7 +1234,7 @@ static int encode_graphed(const rf_encoder_t* enc, const int32_t* ids, const int
       if (enc->graphs.front().exec) (void)hipGraphExecDestroy(enc->graphs.front().exec);
       enc->graphs.erase(enc->graphs.begin());
     }
-    enc->graphs.push_back(rf_encoder::Graph{B, T, ids, lens, o16, (void*)o32, wsp, nullptr, false});
+    enc->graphs.push_back(rf_encoder::Graph{B, T, ids, lens, o16, (void*)o32, wsp, rf_tuning_generation, nullptr, false});
     return RF_ERR_UNSUPPORTED;
   }
   if (g->dead) return RF_ERR_UNSUPPORTED;
@@ -1252,7 +1302,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
   const int tiles = B * T;   // token slots; launch_linear turns them into tiles
   const int32_t* m_ptr = ws.tok_off + B;
 
-  hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off);
+  hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off, ws.ln_ctr);
   {
     int64_t waves = (int64_t)B * T;
     int grid = (int)((waves + 3) / 4);
@@ -1284,7 +1334,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
     const uint4* ff1_t = enc->ff1_t + (size_t)l * I * HID / 8;
     const uint4* ff2_t = enc->ff2_t + (size_t)l * HID * I / 8;
     launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
-                            3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
+                            3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, ws.ln_ctr, st);
     if (T <= 32 * ATT_MAX_KB)
       hipLaunchKernelGGL(k_attention_mfma, dim3(B, c.heads / ATT_HEADS), dim3(256), mfma_lds, st, ws.qkv,
                          ws.tok_off, ws.ctx);
@@ -1293,12 +1343,12 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
                          ws.ctx);
     launch_linear<EPI_BIAS_RES_LN>(ws.ctx, HID, ao_t, (const _Float16*)w.ao_b + (size_t)l * HID, y, HID,
                                    tiles, m_ptr, x, (const _Float16*)w.ln1_g + (size_t)l * HID,
-                                   (const _Float16*)w.ln1_b + (size_t)l * HID, c.ln_eps, ws.pre, st);
+                                   (const _Float16*)w.ln1_b + (size_t)l * HID, c.ln_eps, ws.pre, ws.ln_ctr, st);
     launch_linear<EPI_BIAS_GELU>(y, HID, ff1_t, (const _Float16*)w.ff1_b + (size_t)l * I, ws.ff, I,
-                                 tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
+                                 tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, ws.ln_ctr, st);
     launch_linear<EPI_BIAS_RES_LN>(ws.ff, I, ff2_t, (const _Float16*)w.ff2_b + (size_t)l * HID, x, HID,
                                    tiles, m_ptr, y, (const _Float16*)w.ln2_g + (size_t)l * HID,
-                                   (const _Float16*)w.ln2_b + (size_t)l * HID, c.ln_eps, ws.pre, st);
+                                   (const _Float16*)w.ln2_b + (size_t)l * HID, c.ln_eps, ws.pre, ws.ln_ctr, st);
   }
   hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(192), 0, st, x, ws.tok_off, (_Float16*)out_f16_dev,
                      out_f32_dev);

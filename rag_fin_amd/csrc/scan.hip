@@ -322,7 +322,7 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t st) {
 // ---- tuning knobs (rf_set_tuning / environment at first use) ---------------------------
 extern int rf_tuning_fused;  // api.hip
 extern int rf_tuning_ffn2_ntb, rf_tuning_k384_ntb, rf_tuning_encode_graph;
-extern int rf_tuning_linear_dma, rf_tuning_linear_small, rf_debug_epi, rf_debug_linear_flags;   // encoder.hip
+extern int rf_tuning_ln_tail, rf_tuning_linear_dma, rf_tuning_linear_small, rf_debug_epi, rf_debug_linear_flags;   // encoder.hip
 extern int rf_tuning_wide_variant, rf_tuning_wide_nt, rf_tuning_wide_dbg, rf_tuning_wide_sample_pairs;  // scan_wide.hip
 struct ScanTuning {
   int ring24;           // register-ring depth (fragments) of the dim-384 kernels: 6 | 8 | 12 | 24
@@ -356,6 +356,7 @@ extern "C" int rf_set_tuning(const char* key, int value) {
   else if (!strcmp(key, "encode_graph") && (value == 0 || value == 1)) rf_tuning_encode_graph = value;
   else if (!strcmp(key, "k384_ntb") && (value == 2 || value == 4)) rf_tuning_k384_ntb = value;
   else if (!strcmp(key, "ffn2_ntb") && (value == 2 || value == 4)) rf_tuning_ffn2_ntb = value;
+  else if (!strcmp(key, "ln_tail") && (value == 0 || value == 1)) rf_tuning_ln_tail = value;
   else if (!strcmp(key, "linear_small") && (value == 0 || value == 1)) rf_tuning_linear_small = value;
   else if (!strcmp(key, "linear_dbg") && value >= 0 && value <= 15) rf_debug_linear_flags = value;
   else if (!strcmp(key, "debug_epi") && (value == 0 || value == 1)) rf_debug_epi = value;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rows", type=int, default=100_000)
     ap.add_argument("--calls", type=int, default=300)
     ap.add_argument("--top-k", type=int, default=5)
+    ap.add_argument("--tune", default="", help="rf_set_tuning pairs, e.g. ln_tail=0")
     args = ap.parse_args()
     import torch
     from oracle import encoder as oenc, search as osearch
@@ -52,6 +53,11 @@ def main():
     store.flush()
     store.load()
     rag = VectorRAG(None, embedder=emb, store=store)
+    if args.tune:
+        from rag_fin_amd import _lib
+        for kv in args.tune.split(","):
+            k_, v_ = kv.split("=")
+            _lib.check(_lib.load_library().rf_set_tuning(k_.encode(), int(v_)))
     for q in QUESTIONS * 4:
         rag.search(q, args.top_k)
     lat, t_tok, t_enc, t_search = [], [], [], []

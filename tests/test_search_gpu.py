@@ -323,6 +323,35 @@ def test_wide_sweep_equals_narrow_sweeps(gpu_device, monkeypatch):
     assert torch.equal(i1, torch.cat([p[1] for p in parts])) and torch.equal(e1, torch.cat([p[2] for p in parts]))
 
 
+def test_wide_sweep_variants_stay_exact(gpu_device):
+    """The four forms of the batch-256 sweep (register-staged, LDS-DMA with 4 or 8 waves, 8 waves
+    with AGPR-pinned queries) and both load policies: ids, ranks and fp64 scores equal the
+    oracle's for every one (the all-VGPR default once returned wrong tiles: an inline-asm
+    v_max3 read MFMA results without the wait states -- this is the test that caught it)."""
+    import torch
+    from rag_fin_amd import _lib
+    lib = _lib.load_library()
+    c = osearch.synth_unit_rows(150_000, 384, 51)
+    q16 = osearch.synth_unit_rows(256, 384, 52)
+    ix = make_index(c, gpu_device)
+    os_, oi = c_oracle.search(q16, c, 10)
+    q = torch.from_numpy(q16).to(gpu_device)
+    try:
+        for variant in (0, 1, 3, 2):
+            for nt in (0, 1):
+                _lib.check(lib.rf_set_tuning(b"wide_variant", variant))
+                _lib.check(lib.rf_set_tuning(b"wide_nt", nt))
+                for _ in range(2):
+                    s, i, e, f = ix.search_raw(q, 10, want_exact=True)
+                torch.cuda.synchronize()
+                assert int(f.abs().sum()) == 0, (variant, nt)
+                assert np.array_equal(i.cpu().numpy(), oi), (variant, nt)
+                assert np.array_equal(e.cpu().numpy(), os_), (variant, nt)
+    finally:
+        lib.rf_set_tuning(b"wide_variant", 2)
+        lib.rf_set_tuning(b"wide_nt", 1)
+
+
 @pytest.mark.parametrize("n,k", [(5_000, 1000), (30_000, 200), (100, 1000)])
 def test_limits_above_64_are_paged_exactly(gpu_device, n, k):
     """graph_cons.hybrid_query_simple searches with limit=1000 (graph_cons.py:275-281):

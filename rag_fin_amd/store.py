@@ -28,6 +28,11 @@ import numpy as np
 
 from . import _lib
 
+import os as _os
+# RAGFIN_ZERO_COPY=0: search_host copies results with async memcpys instead of letting the merge kernel
+# store into the pinned host buffers (A/B switch)
+_ZERO_COPY = _os.environ.get("RAGFIN_ZERO_COPY", "1") != "0"
+
 SCALAR_FIELDS = ("id", "text", "period", "chunk_type", "statement_type", "primary_value")
 
 
@@ -252,23 +257,31 @@ class GpuIndex:
                     exact[bad] = e2
         return scores, ids, exact
 
+    ZERO_COPY_MAX = 4096   # B * k up to which search_host lets the kernel write into host memory
+
     def search_host(self, q16, k: int):
         """search() whose results land on the host with ONE synchronisation: scores, ids and
         flags are copied into cached pinned buffers asynchronously.  -> (scores f32 [B,k],
         ids i64 [B,k]) numpy views (valid until the next call with the same shape)."""
         torch = _torch()
         with self._lock:
-            scores, ids, _, flags = self.search_raw(q16, k)
-            B = scores.shape[0]
+            B = q16.shape[0]
             key = (B, k)
             bufs = self._host_bufs.get(key)
             if bufs is None:
                 bufs = self._host_bufs[key] = (torch.empty((B, k), dtype=torch.float32, pin_memory=True),
                                                torch.empty((B, k), dtype=torch.int64, pin_memory=True),
                                                torch.empty((B,), dtype=torch.int32, pin_memory=True))
-            bufs[0].copy_(scores, non_blocking=True)
-            bufs[1].copy_(ids, non_blocking=True)
-            bufs[2].copy_(flags, non_blocking=True)
+            if B * k <= self.ZERO_COPY_MAX and _ZERO_COPY:
+                # query-sized results: the merge kernel stores straight into the pinned host buffers
+                # (host-coherent memory, mapped at the same address on the device) -- no copy commands,
+                # only the synchronisation
+                self.search_raw(q16, k, out=(bufs[0], bufs[1], None, bufs[2]))
+            else:
+                scores, ids, _, flags = self.search_raw(q16, k)
+                bufs[0].copy_(scores, non_blocking=True)
+                bufs[1].copy_(ids, non_blocking=True)
+                bufs[2].copy_(flags, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
             if bool(bufs[2].any()):
                 bad = torch.nonzero(bufs[2] != 0).flatten()

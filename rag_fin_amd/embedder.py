@@ -244,9 +244,14 @@ class Embedder:
         sentences = list(sentences)
         n = len(sentences)
         out = torch.empty((n, self.dim), dtype=torch.float16, device=self.device)
+        if n == 0:
+            return out
         chunk_texts = 4096
-        for c0 in range(0, n, chunk_texts):
-            part = sentences[c0:c0 + chunk_texts]
+        # the first chunk is a quarter of the others: nothing overlaps ITS tokenisation, so the
+        # GPU should get its first buckets early
+        starts = [0] + list(range(min(n, chunk_texts // 4), n, chunk_texts))
+        for ci, c0 in enumerate(starts):
+            part = sentences[c0:(starts[ci + 1] if ci + 1 < len(starts) else n)]
             if hasattr(self.tokenizer, "batch_native"):
                 all_ids, all_lens = self.tokenizer.batch_native(part, self.max_seq_length)
             else:
@@ -278,7 +283,7 @@ class Embedder:
                                   lens=torch.empty(chunk_texts, dtype=torch.int32).pin_memory(),
                                   order=torch.empty(chunk_texts, dtype=torch.int64).pin_memory(),
                                   done=None) for _ in range(2)]
-            pb = self._pin[(c0 // chunk_texts) & 1]
+            pb = self._pin[ci & 1]
             if pb["done"] is not None:
                 pb["done"].synchronize()      # its previous upload has left the buffers
             pb["ids"][:m * Tc].view(m, Tc).copy_(torch.from_numpy(all_ids))

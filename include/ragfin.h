@@ -89,6 +89,10 @@ int rf_normalize_f32_to_f16(const float* in_dev, int64_t n, int dim, int normali
  *            the cross-shard merge
  * flags_dev  uint32 [B]    RF_FLAG_* bits; 0 means the result is proven equal
  *            to the exact ranking by (score desc, id asc)
+ * The four output pointers may also be device-visible host memory (pinned,
+ * host-coherent): the last kernel then stores the result straight into it
+ * and the caller only synchronises the stream -- worthwhile for query-sized
+ * results (no copy command between the kernel and the host).
  */
 size_t rf_search_workspace_bytes(const rf_index_t* ix);
 int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_base,

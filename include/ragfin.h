@@ -139,8 +139,12 @@ int rf_merge_shards_packed(const int64_t* packed_dev, int W, int B, int k,
  * the step time, so the lanes share it.) */
 int rf_merge_shards_group(const int64_t* packed_dev, int W, int L, int B, int k,
                           float* scores_out_dev, int64_t* ids_out_dev, void* stream);
-/* Tuning hook (experiments / A-B runs in one process): key in {"ring24",
- * "emit_wgs_per_cu", "sample_bpw"}.  No reference counterpart. */
+/* Tuning hook (experiments / A-B runs in one process; process-wide, not thread-safe against
+ * concurrent searches).  Keys -- search: "ring24" (6|8|12|24), "emit_wgs_per_cu" (0..4),
+ * "sample_bpw" (1..8), "fused", "qreg", "search_graph" (0|1), "wide_variant" (0..3), "wide_nt",
+ * "wide_sample_pairs" (1..8), "wide_dbg"; encoder: "linear_dma" (0..3), "linear_small", "ln_tail",
+ * "encode_graph" (0|1), "k384_ntb", "ffn2_ntb" (2|4), "linear_dbg", "debug_epi".  Unknown keys or
+ * values return RF_ERR_INVALID.  Cached graphs are dropped on every change.  No reference counterpart. */
 int rf_set_tuning(const char* key, int value);
 /* Diagnostic hook: byte offset of a named array ("pmax", "cand", "thr") inside a search
  * workspace, (size_t)-1 if unknown.  Used by tools/bench_wide.py to read clock stamps. */

@@ -15,10 +15,17 @@ batches in flight work the same way (the all-gathers of the lanes share one
 communicator and are issued in the same order on every rank).
 Default = STRONG scaling: the metric's 1M-row corpus is split over the N GPUs (rank r
 holds rows [r N/W, (r+1) N/W)), so `value` -- queries/sec of the whole job -- grows
-with N until the per-step latency floor (three enqueues + collective, ~50 us) is
+with N until the per-step launch floor (six launches, ~31 us with 8 batches in flight) is
 reached; at 8 GPUs a shard is 125k rows = 15 us of scan.  `--scaling weak` keeps
 --rows rows PER GPU instead (capacity scaling, BASELINE configs[4] style: the same 64
 queries against an N-times larger corpus; ideal = flat value, `rows_per_s` grows).
+
+Beside `value` (4 batches in flight, inputs resident in HBM) the one JSON line carries:
+`serial` (one batch at a time), `roofline` (emit sweep, HIP events, PMC traffic from
+profiles/), `stage_ms`, `batch256` (BASELINE configs[2], two batches in flight),
+`pcie_inclusive` (queries from / results to pinned host memory; never `value`),
+recall / exactness against the C oracle (at N > 1 also of the merged answer:
+`global_*`), and `cpu_baseline` (numpy BLAS port on the host cores, N = 1 only).
 """
 from __future__ import annotations
 

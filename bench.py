@@ -452,12 +452,7 @@ def main():
             result["checked_queries"] = nq
             if global_oracle is not None and res is not None:
                 gs, gid = global_oracle   # [world, nq, k]
-                exp_i = np.empty((nq, k), dtype=np.int64)
-                exp_s = np.empty((nq, k), dtype=np.float64)
-                for b in range(nq):
-                    cs, ci = gs[:, b, :].reshape(-1), gid[:, b, :].reshape(-1)
-                    order = np.lexsort((ci, -cs))[:k]
-                    exp_i[b], exp_s[b] = ci[order], cs[order]
+                exp_s, exp_i = osearch.merge_shards(gs, gid, k)   # (score desc, id asc), tests/test_oracle_search.py
                 got_i = res[1][:nq].cpu().numpy()
                 got_s = res[0][:nq].cpu().numpy().astype(np.float64)
                 result["global_ids_ranks_exact"] = bool(np.array_equal(got_i, exp_i))

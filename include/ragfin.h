@@ -17,6 +17,12 @@
  *     stream: work is enqueued on `stream` (a hipStream_t passed as void*) in
  *     order, so a caller may capture it into a hipGraph.
  *   - device pointers must be 16-byte aligned.
+ *   - threading: an rf_index_t / rf_encoder_t may be used by any number of host threads at
+ *     once as long as each concurrent call has its OWN workspace (and normally its own
+ *     stream); the handles hold no per-call state.  rf_index_add_f16 / rf_index_reset must
+ *     not run concurrently with a search on the same index.  A process may hold indexes and
+ *     encoders on several devices; the calling thread's current HIP device must be the
+ *     handle's device (hipSetDevice / torch.cuda.device).
  */
 #ifndef RAGFIN_H
 #define RAGFIN_H
@@ -47,6 +53,10 @@ typedef struct rf_encoder rf_encoder_t;
 
 /* ---- library ---------------------------------------------------------- */
 int rf_version(void);
+/* Hex digest of the sources this binary was compiled from (every .hip / .h / .cpp under csrc/ and
+ * this header), stamped at build time; rag_fin_amd/_lib.py compares it with the sources on disk and
+ * rebuilds (hipcc present) or refuses to load (hipcc absent) a stale library. */
+const char* rf_build_id(void);
 const char* rf_last_error(void);
 /* RF_OK when `device` is a gfx950 part the kernels were built for. */
 int rf_device_check(int device);
@@ -127,34 +137,39 @@ int rf_search_exhaustive_after(const rf_index_t* ix, const void* q_dev, int B, i
  * reference is single-process); see SURVEY.md 8e. */
 int rf_merge_shards(const double* exact_dev, const int64_t* ids_dev, int W, int B, int k,
                     float* scores_out_dev, int64_t* ids_out_dev, void* stream);
-/* Same merge on the all-gather's own layout: packed_dev int64 [W][2][B][k], plane 0 = the
- * fp64 ranking scores (bit patterns), plane 1 = the global row ids -- what each rank gets
- * when rf_search writes exact_dev / ids_dev into the two halves of ONE send buffer, so that
- * no repacking kernel runs between the scan, the collective and the merge. */
+/* Same merge on the all-gather's own layout.  Each rank's send buffer is
+ * rf_packed_shard_words(B, k) int64 words:
+ *   [0, B k)        the fp64 ranking scores (bit patterns)   <- rf_search exact_dev
+ *   [B k, 2 B k)    the global row ids                       <- rf_search ids_dev
+ *   [2 B k, ...)    uint32 flags[B] (RF_FLAG_*), zero-padded <- rf_search flags_dev
+ * so rf_search writes its outputs straight into ONE send buffer and no repacking kernel runs
+ * between the scan, the collective and the merge.  packed_dev = the gathered [W] buffers.
+ * flags_out_dev (nullable) uint32 [B]: OR of the W shards' flags -- identical on every rank, so
+ * all ranks agree on which queries to re-run through rf_search_exhaustive (a query whose LOCAL
+ * answer was unproven on ANY shard has an unproven merged answer). */
+size_t rf_packed_shard_words(int B, int k);
 int rf_merge_shards_packed(const int64_t* packed_dev, int W, int B, int k,
-                           float* scores_out_dev, int64_t* ids_out_dev, void* stream);
-/* The same for L batches in flight whose per-shard results travelled in ONE all-gather:
- * packed_dev int64 [W][L][2][B][k] -> scores [L][B][k], ids [L][B][k], one launch.  (The
- * collective costs ~30 us of host time per call: with 125 k-row shards it, not the scan, sets
- * the step time, so the lanes share it.) */
-int rf_merge_shards_group(const int64_t* packed_dev, int W, int L, int B, int k,
-                          float* scores_out_dev, int64_t* ids_out_dev, void* stream);
-/* Tuning hook (experiments / A-B runs in one process; process-wide, not thread-safe against
- * concurrent searches).  Keys -- search: "ring24" (6|8|12|24), "emit_wgs_per_cu" (0..4),
- * "sample_bpw" (1..8), "fused", "qreg", "search_graph" (0|1), "wide_variant" (0..3), "wide_nt",
- * "wide_sample_pairs" (1..8), "wide_dbg"; encoder: "linear_dma" (0..3), "linear_small", "ln_tail",
- * "encode_graph" (0|1), "k384_ntb", "ffn2_ntb" (2|4), "linear_dbg", "debug_epi".  Unknown keys or
- * values return RF_ERR_INVALID.  Cached graphs are dropped on every change.  No reference counterpart. */
-int rf_set_tuning(const char* key, int value);
-/* Diagnostic hook: byte offset of a named array ("pmax", "cand", "thr") inside a search
- * workspace, (size_t)-1 if unknown.  Used by tools/bench_wide.py to read clock stamps. */
-size_t rf_debug_workspace_offset(const char* field);
-/* Diagnostic hook: a device buffer (>= 64 KiB, or NULL to switch off) that instrumented
- * kernels fill with clock stamps (encoder k_linear_dma: 8 floats per wave). */
-int rf_debug_set_buffer(void* dev_ptr);
+                           float* scores_out_dev, int64_t* ids_out_dev,
+                           uint32_t* flags_out_dev, void* stream);
 /* Test hook: raw MFMA scan scores fp32 [B, n] for the first n rows. */
 int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,
                     float* out_dev, void* stream);
+
+#ifdef RF_EXPERIMENTS
+/* ---- experiments build only (python -m rag_fin_amd.build --experiments ->
+ * libragfin_hip_exp.so; used by tools/, never by the product or the tests) -------------------
+ * The shipped library has no run-time tuning surface: the knobs are compile-time constants
+ * (csrc/rf_internal.h).  In the experiments build they are process-wide ints, NOT thread-safe
+ * against concurrent searches.  Keys: "ring24" (6|8|12|24), "emit_wgs_per_cu" (0..4),
+ * "sample_bpw" (1..8), "wide_sample_pairs" (1..8), "wide_dbg"; encoder: "linear_dma" (0..3),
+ * "linear_small", "encode_graph" (0|1), "k384_ntb", "ffn2_ntb" (2|4), "linear_dbg", "debug_epi". */
+int rf_set_tuning(const char* key, int value);
+/* byte offset of a named array ("pmax", "cand", "thr") inside a search workspace */
+size_t rf_debug_workspace_offset(const char* field);
+/* a device buffer (>= 64 KiB, or NULL to switch off) that instrumented kernels fill with
+ * clock stamps (encoder k_linear_dma: 8 floats per wave) */
+int rf_debug_set_buffer(void* dev_ptr);
+#endif
 
 /* ---- embedder: replaces SentenceTransformer('all-MiniLM-L6-v2').encode ----
  * Reference: vector_rag_mcp/main.py:41,50; retrieve.py:14,27;
@@ -200,9 +215,9 @@ int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cfg,
 int rf_encoder_destroy(rf_encoder_t* enc);
 size_t rf_encode_workspace_bytes(const rf_encoder_t* enc, int B, int T);
 /* Query-sized calls (B * T <= 1024): the launch sequence is captured once per (B, T, buffer
- * pointers) into a hipGraph owned by the encoder handle and replayed on `stream` afterwards
- * (RF_ENCODE_GRAPH=0 / rf_set_tuning("encode_graph", 0) keeps plain launches); callers that
- * want the replay keep their buffers at fixed addresses (rag_fin_amd.embedder does).
+ * pointers) into a hipGraph owned by the encoder handle and replayed on `stream`
+ * afterwards; callers that want the replay keep their buffers at fixed addresses
+ * (rag_fin_amd.embedder does).
  * ids_dev int32 [B, T] (padded), lens_dev int32 [B] (valid tokens per row).
  * out_f16_dev fp16 [B, H] and/or out_f32_dev fp32 [B, H] (either nullable):
  * masked mean-pool + L2-normalise of the last hidden state. */

@@ -43,6 +43,7 @@ class EncoderWeights(Structure):
 # name -> (restype, argtypes); every symbol include/ragfin.h declares
 SIGNATURES = {
     "rf_version": (c_int, []),
+    "rf_build_id": (c_char_p, []),
     "rf_last_error": (c_char_p, []),
     "rf_device_check": (c_int, [c_int]),
     "rf_index_storage_bytes": (c_size_t, [c_int, c_int64]),
@@ -66,16 +67,13 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rf_merge_shards": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p]),
-    "rf_merge_shards_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "rf_merge_shards_group": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rf_packed_shard_words": (c_size_t, [c_int, c_int]),
+    "rf_merge_shards_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rf_tokenizer_create": (c_int, [POINTER(c_void_p), c_char_p, c_size_t, c_int, c_int]),
     "rf_tokenizer_destroy": (c_int, [c_void_p]),
     "rf_tokenizer_set_punctuation": (c_int, [c_void_p, c_void_p, c_int]),
     "rf_tokenizer_special_ids": (c_int, [c_void_p, c_void_p]),
     "rf_tokenize_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
-    "rf_set_tuning": (c_int, [c_char_p, c_int]),
-    "rf_debug_workspace_offset": (c_size_t, [c_char_p]),
-    "rf_debug_set_buffer": (c_int, [c_void_p]),
     "rf_debug_scores": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "rf_encoder_storage_bytes": (c_size_t, [POINTER(EncoderConfig)]),
     "rf_encoder_create": (c_int, [POINTER(c_void_p), POINTER(EncoderConfig),
@@ -86,22 +84,37 @@ SIGNATURES = {
                           c_size_t, c_void_p]),
 }
 
+# present only in the experiments build (libragfin_hip_exp.so, tools/): bound when exported
+EXPERIMENT_SIGNATURES = {
+    "rf_set_tuning": (c_int, [c_char_p, c_int]),
+    "rf_debug_workspace_offset": (c_size_t, [c_char_p]),
+    "rf_debug_set_buffer": (c_int, [c_void_p]),
+}
+
 _lib = None
 
 
 def library_path() -> str:
-    # RAGFIN_LIB: load an alternative build of the same ABI (tuning experiments)
-    return os.environ.get("RAGFIN_LIB") or _build.LIB_PATH
+    # RAGFIN_LIB=exp: the experiments build (tools/); any other value: an explicit path
+    v = os.environ.get("RAGFIN_LIB")
+    if v == "exp":
+        return _build.EXP_LIB_PATH
+    return v or _build.LIB_PATH
 
 
 def load_library() -> ctypes.CDLL:
-    """Load (building first if the .so is absent and hipcc is present)."""
+    """Load the library, making sure it was built from the sources on disk: a missing or stale
+    .so is rebuilt when hipcc is present and refused when it is not (no silent old kernels)."""
     global _lib
     if _lib is not None:
         return _lib
     path = library_path()
-    if not os.path.exists(path):
-        _build.build_lib()  # raises if hipcc is missing -- no fallback
+    in_tree = path in (_build.LIB_PATH, _build.EXP_LIB_PATH)
+    exp = path == _build.EXP_LIB_PATH
+    if in_tree and _build.have_hipcc():
+        _build.build_lib(experiments=exp)   # no-op when objects and digest are current
+    elif not os.path.exists(path):
+        _build.build_lib(experiments=exp)   # raises: hipcc is missing -- no fallback
     # torch ships its own libamdhip64; load it FIRST so that this library binds to the
     # same HIP runtime instance (loaded the other way round, the two runtimes disagree
     # about device visibility: rf_device_check saw "no HIP device" on a GPU box)
@@ -114,6 +127,18 @@ def load_library() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENT_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
+    if in_tree:
+        have = (lib.rf_build_id() or b"").decode()
+        want = _build.source_digest(exp)
+        if have != want:
+            raise RuntimeError(f"{path} was built from other sources (build id {have}, sources {want}) and "
+                               "hipcc is not available to rebuild it; run `python -m rag_fin_amd.build` "
+                               "where the ROCm toolchain is")
     _lib = lib
     return lib
 

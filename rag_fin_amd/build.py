@@ -3,9 +3,20 @@
 `python -m rag_fin_amd.build` or `rag_fin_amd.build.build_lib()`.  hipcc
 cross-compiles without a GPU, so this runs in the CPU-only container; the built
 .so travels to the GPU box with the source snapshot.
+
+Two flavours share the sources:
+  libragfin_hip.so      the product: no run-time tuning surface (knobs are compile-time
+                        constants), only the kernels the product dispatches to
+  libragfin_hip_exp.so  `--experiments` (-DRF_EXPERIMENTS): adds rf_set_tuning, the diagnostic
+                        hooks and the ablation / alternative kernel instantiations that
+                        tools/ A/B against each other; loaded through RAGFIN_LIB by tools only
+
+The library carries a digest of its sources (rf_build_id); _lib.load_library() compares it
+with source_digest() so that a stale .so is rebuilt or refused, never silently loaded.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -16,8 +27,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libragfin_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
-SOURCES = ["index.hip", "scan.hip", "scan_fused.hip", "scan_wide.hip", "merge.hip", "api.hip", "encoder.hip",
-           "tokenizer.cpp"]
+EXP_LIB_PATH = os.path.join(CSRC, "libragfin_hip_exp.so")
+SOURCES = ["index.hip", "scan.hip", "scan_wide.hip", "merge.hip", "api.hip", "encoder.hip", "tokenizer.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -28,6 +39,27 @@ def _hipcc() -> str:
     return exe
 
 
+def have_hipcc() -> bool:
+    return os.path.exists(shutil.which("hipcc") or "/opt/rocm/bin/hipcc")
+
+
+def _headers() -> list[str]:
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    hs.append(os.path.normpath(os.path.join(HERE, "..", "include", "ragfin.h")))
+    return hs
+
+
+def source_digest(experiments: bool = False) -> str:
+    """sha256 over the compile flags and every source / header the library is built from."""
+    h = hashlib.sha256()
+    h.update((" ".join(FLAGS) + (" -DRF_EXPERIMENTS" if experiments else "")).encode())
+    for path in [os.path.join(CSRC, s) for s in SOURCES + ["build_id.cpp"]] + _headers():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps: list[str]) -> bool:
     if not os.path.exists(target):
         return True
@@ -35,37 +67,46 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+def build_lib(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(HERE, "..", "include", "ragfin.h"))
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    objs = [os.path.splitext(s)[0] + ".o" for s in srcs]
+    headers = _headers()
+    suffix = ".exp.o" if experiments else ".o"
+    flags = FLAGS + (["-DRF_EXPERIMENTS"] if experiments else [])
+    out = EXP_LIB_PATH if experiments else LIB_PATH
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    objs = [os.path.splitext(s)[0] + suffix for s in srcs]
 
-    def compile_one(pair):
-        src, obj = pair
-        if not force and not _stale(obj, [src] + headers):
-            return
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+            raise RuntimeError(f"{' '.join(cmd[:1] + cmd[-3:])} failed:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
+    def compile_one(pair):
+        src, obj = pair
+        if force or _stale(obj, [src] + headers):
+            run([hipcc, *flags, "-c", src, "-o", obj])
+
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
-    if force or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB_PATH
+    # the digest TU: recompiled whenever the digest it carries differs from the sources'
+    digest = source_digest(experiments)
+    id_obj = os.path.join(CSRC, "build_id" + suffix)
+    id_txt = id_obj + ".id"
+    have = open(id_txt).read().strip() if os.path.exists(id_txt) else ""
+    relink = force or _stale(out, objs)
+    if have != digest or not os.path.exists(id_obj):
+        run([hipcc, *flags, f'-DRF_BUILD_ID="{digest}"', "-c", os.path.join(CSRC, "build_id.cpp"), "-o", id_obj])
+        with open(id_txt, "w") as f:
+            f.write(digest)
+        relink = True
+    if relink:
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, id_obj])
+    return out
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_lib(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

@@ -17,9 +17,6 @@ static size_t carve(unsigned char* base, rf_workspace* ws) {
   float* thr = (float*)take(RF_QWIDE * sizeof(float));
   float* eps = (float*)take(RF_QWIDE * sizeof(float));
   uint32_t* cnt = (uint32_t*)take((size_t)RF_QWIDE * RF_CAND_SHARDS * sizeof(uint32_t));
-  uint32_t* gmax = (uint32_t*)take((size_t)RF_QWIDE * RF_MAX_K * sizeof(uint32_t));
-  uint32_t* bar = (uint32_t*)take(16 * sizeof(uint32_t));
-  const size_t ctl_bytes = off;
   float* pmax = (float*)take((size_t)RF_QWIDE * RF_SAMPLE_WGS * sizeof(float));
   uint2* cand = (uint2*)take((size_t)RF_QWIDE * RF_CAND_SHARDS * RF_SHARD_CAP * sizeof(uint2));
   double* exs = (double*)take((size_t)RF_QCHUNK * RF_EX_WGS * RF_MAX_K * sizeof(double));
@@ -28,9 +25,6 @@ static size_t carve(unsigned char* base, rf_workspace* ws) {
     ws->thr = thr;
     ws->eps = eps;
     ws->cand_cnt = cnt;
-    ws->gmax = gmax;
-    ws->bar = bar;
-    ws->ctl_bytes = ctl_bytes;
     ws->pmax = pmax;
     ws->cand = cand;
     ws->ex_score = exs;
@@ -39,6 +33,7 @@ static size_t carve(unsigned char* base, rf_workspace* ws) {
   return off;
 }
 
+#ifdef RF_EXPERIMENTS
 // Diagnostic hook: byte offset of a named workspace array ("pmax", "cand", "thr").
 extern "C" size_t rf_debug_workspace_offset(const char* field) {
   unsigned char* base = (unsigned char*)(uintptr_t)4096;   // never dereferenced
@@ -49,6 +44,7 @@ extern "C" size_t rf_debug_workspace_offset(const char* field) {
   if (field && !strcmp(field, "thr")) return (size_t)((unsigned char*)ws.thr - base);
   return (size_t)-1;
 }
+#endif
 
 extern "C" size_t rf_search_workspace_bytes(const rf_index_t* ix) {
   (void)ix;
@@ -84,41 +80,6 @@ static int check_search_args(const char* fn, const rf_index_t* ix, const void* q
 static void fill_empty(int B, int k, float* scores, int64_t* ids, double* exact, uint32_t* flags,
                        hipStream_t st);
 
-// Scan pipeline: three kernels (sample -> threshold -> emit; the default) or the
-// single-launch fused scan (RF_FUSED=1 / rf_set_tuning("fused", 1)).  On MI355X the
-// fused form measured SLOWER: its in-kernel hand-off costs 3-4 dependent global
-// round trips of ~8 us each under the saturating stream.
-int rf_tuning_fused = -1;
-static bool use_fused() {
-  if (rf_tuning_fused < 0) {
-    const char* v = getenv("RF_FUSED");
-    rf_tuning_fused = (v && v[0] == '1') ? 1 : 0;
-  }
-  return rf_tuning_fused != 0;
-}
-
-// RF_WIDE=0 answers large batches with 64-query sweeps only (A/B runs)
-static bool use_wide() {
-  static const bool on = [] {
-    const char* v = getenv("RF_WIDE");
-    return !(v && v[0] == '0');
-  }();
-  return on;
-}
-
-// The control block (counters, group maxima, hand-off words) must be zero when a
-// search starts.  k_merge leaves it zero for the next call; a workspace this index
-// has not used before is zeroed here once.
-static int prepare_workspace(const rf_index* ix, const void* base, const rf_workspace& ws,
-                             hipStream_t st) {
-  for (int i = 0; i < 8; ++i)
-    if (ix->ws_clean[i] == base) return RF_OK;
-  RF_HIP(hipMemsetAsync((void*)base, 0, ws.ctl_bytes, st));
-  ix->ws_clean[ix->ws_clean_next] = base;
-  ix->ws_clean_next = (ix->ws_clean_next + 1) & 7;
-  return RF_OK;
-}
-
 __global__ void k_fill_empty(int n, int B, float* scores, int64_t* ids, double* exact,
                              uint32_t* flags) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -137,70 +98,9 @@ static void fill_empty(int B, int k, float* scores, int64_t* ids, double* exact,
                      exact, flags);
 }
 
-int rf_tuning_generation = 0;
-// OFF by default (RF_SEARCH_GRAPH=1 / rf_set_tuning("search_graph", 1) to try it): measured no gain --
-// 20.7 vs 20.8 us/step on a 100 k-row corpus with 4 batches in flight, 40.2 vs 37.9 us on a 125 k-row
-// shard step: the step is bound by the dependent-kernel latency on the GPU, not by the host launches.
-int rf_tuning_search_graph = -1;
-
 static int search_enqueue(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_base, float* scores_dev,
                           int64_t* ids_dev, double* exact_dev, uint32_t* flags_dev, void* workspace_dev,
                           hipStream_t st);
-
-// Replay of a cached hipGraph for a call whose every buffer (and the corpus size, and the tuning
-// settings) is the one of an earlier call.  First call with a key: plain launches; second: capture
-// on a private stream + replay; later: replay.  RF_ERR_UNSUPPORTED = "use plain launches".
-static int search_graphed(const rf_index_t* ix, const void* q, int B, int k, int64_t id_base, float* scores,
-                          int64_t* ids, double* exact, uint32_t* flags, void* wsp, hipStream_t st) {
-  if (rf_tuning_search_graph < 0) {
-    const char* v = getenv("RF_SEARCH_GRAPH");
-    rf_tuning_search_graph = (v && v[0] == '1') ? 1 : 0;
-  }
-  if (!rf_tuning_search_graph || use_fused()) return RF_ERR_UNSUPPORTED;
-  std::lock_guard<std::mutex> lock(ix->graph_mu);
-  rf_index::Graph* g = nullptr;
-  for (auto& e : ix->graphs)
-    if (e.q == q && e.B == B && e.k == k && e.id_base == id_base && e.size == ix->size && e.scores == scores &&
-        e.ids == ids && e.exact == exact && e.flags == flags && e.ws == wsp && e.tuning_gen == rf_tuning_generation) {
-      g = &e;
-      break;
-    }
-  if (!g) {
-    if (ix->graphs.size() >= 32) {
-      if (ix->graphs.front().exec) (void)hipGraphExecDestroy(ix->graphs.front().exec);
-      ix->graphs.erase(ix->graphs.begin());
-    }
-    ix->graphs.push_back(rf_index::Graph{q, B, k, id_base, ix->size, scores, ids, exact, flags, wsp,
-                                         rf_tuning_generation, nullptr, false});
-    return RF_ERR_UNSUPPORTED;
-  }
-  if (g->dead) return RF_ERR_UNSUPPORTED;
-  if (!g->exec) {
-    if (!ix->cap_stream && hipStreamCreateWithFlags(&ix->cap_stream, hipStreamNonBlocking) != hipSuccess) {
-      g->dead = true;
-      return RF_ERR_UNSUPPORTED;
-    }
-    if (hipStreamBeginCapture(ix->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      g->dead = true;
-      return RF_ERR_UNSUPPORTED;
-    }
-    const int rc = search_enqueue(ix, q, B, k, id_base, scores, ids, exact, flags, wsp, ix->cap_stream);
-    hipGraph_t graph = nullptr;
-    const hipError_t e1 = hipStreamEndCapture(ix->cap_stream, &graph);
-    hipGraphExec_t exec = nullptr;
-    if (rc != RF_OK || e1 != hipSuccess || !graph ||
-        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-      if (graph) (void)hipGraphDestroy(graph);
-      (void)hipGetLastError();
-      g->dead = true;
-      return RF_ERR_UNSUPPORTED;
-    }
-    (void)hipGraphDestroy(graph);
-    g->exec = exec;
-  }
-  RF_HIP(hipGraphLaunch(g->exec, st));
-  return RF_OK;
-}
 
 extern "C" int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_base,
                          float* scores_dev, int64_t* ids_dev, double* exact_dev,
@@ -210,10 +110,6 @@ extern "C" int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, 
                              workspace_bytes);
   if (rc != RF_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (ix->size > 0) {
-    rc = search_graphed(ix, q_dev, B, k, id_base, scores_dev, ids_dev, exact_dev, flags_dev, workspace_dev, st);
-    if (rc != RF_ERR_UNSUPPORTED) return rc;
-  }
   return search_enqueue(ix, q_dev, B, k, id_base, scores_dev, ids_dev, exact_dev, flags_dev, workspace_dev, st);
 }
 
@@ -228,10 +124,8 @@ static int search_enqueue(const rf_index_t* ix, const void* q_dev, int B, int k,
   }
   rf_workspace ws;
   carve((unsigned char*)workspace_dev, &ws);
-  rc = prepare_workspace(ix, workspace_dev, ws, st);
-  if (rc != RF_OK) return rc;
   const int dim = ix->dim;
-  const bool wide_ok = !use_fused() && rf_wide_supported(ix) && use_wide();
+  const bool wide_ok = rf_wide_supported(ix);
   for (int q0 = 0; q0 < B;) {
     const int left = B - q0;
     // more than one 64-query sweep left and dim 384: one wide sweep of up to 256 queries
@@ -253,9 +147,6 @@ static int search_enqueue(const rf_index_t* ix, const void* q_dev, int B, int k,
       rc = rf_launch_threshold(ix, qc, nb, k, P, ws, st);
       if (rc != RF_OK) return rc;
       rc = rf_launch_wide_emit(ix, qc, nb, ws, st);
-      if (rc != RF_OK) return rc;
-    } else if (use_fused()) {
-      rc = rf_launch_fused(ix, qc, nb, JB, k, ws, st);
       if (rc != RF_OK) return rc;
     } else {
       int P = 0;
@@ -296,19 +187,12 @@ extern "C" int rf_search_profile(const rf_index_t* ix, const void* q_dev, int B,
   const int nb = B < RF_QCHUNK ? B : RF_QCHUNK;
   const int JB = nb <= 32 ? 1 : 2;
   int P = 0;
-  rc = prepare_workspace(ix, workspace_dev, ws, st);
   RF_HIP(hipEventRecord(ev[0], st));
-  if (rc == RF_OK && !use_fused() && ix->size > RF_SMALL_ROWS)
-    rc = rf_launch_sample(ix, q_dev, nb, JB, ws, &P, st);
+  if (ix->size > RF_SMALL_ROWS) rc = rf_launch_sample(ix, q_dev, nb, JB, ws, &P, st);
   RF_HIP(hipEventRecord(ev[1], st));
-  if (rc == RF_OK && !use_fused()) rc = rf_launch_threshold(ix, q_dev, nb, k, P, ws, st);
-  // RF_DEBUG_NO_HITS=1 (timing experiments only, results wrong): thresholds of 3.4e38, so the
-  // emit sweep appends nothing -- what the candidate path costs is the difference
-  static const bool no_hits = getenv("RF_DEBUG_NO_HITS") != nullptr;
-  if (no_hits) RF_HIP(hipMemsetAsync(ws.thr, 0x7f, RF_QCHUNK * sizeof(float), st));
+  if (rc == RF_OK) rc = rf_launch_threshold(ix, q_dev, nb, k, P, ws, st);
   RF_HIP(hipEventRecord(ev[2], st));
-  if (rc == RF_OK)
-    rc = use_fused() ? rf_launch_fused(ix, q_dev, nb, JB, k, ws, st) : rf_launch_emit(ix, q_dev, nb, JB, ws, st);
+  if (rc == RF_OK) rc = rf_launch_emit(ix, q_dev, nb, JB, ws, st);
   RF_HIP(hipEventRecord(ev[3], st));
   if (rc == RF_OK)
     rc = rf_launch_merge(ix, q_dev, nb, k, id_base, ws, scores_dev, ids_dev, exact_dev, flags_dev, st);
@@ -371,30 +255,27 @@ extern "C" int rf_merge_shards(const double* exact_dev, const int64_t* ids_dev, 
     rf_set_error("rf_merge_shards: bad argument");
     return RF_ERR_INVALID;
   }
-  return rf_launch_merge_shards(exact_dev, ids_dev, (size_t)B * k, 0, W, 1, B, k, scores_out_dev, ids_out_dev,
-                                (hipStream_t)stream);
+  return rf_launch_merge_shards(exact_dev, ids_dev, (size_t)B * k, W, B, k, scores_out_dev, ids_out_dev, nullptr, 0,
+                                nullptr, (hipStream_t)stream);
+}
+
+extern "C" size_t rf_packed_shard_words(int B, int k) {
+  if (B <= 0 || k <= 0) return 0;
+  return (size_t)2 * B * k + ((size_t)B + 1) / 2;
 }
 
 extern "C" int rf_merge_shards_packed(const int64_t* packed_dev, int W, int B, int k,
-                                      float* scores_out_dev, int64_t* ids_out_dev, void* stream) {
+                                      float* scores_out_dev, int64_t* ids_out_dev,
+                                      uint32_t* flags_out_dev, void* stream) {
   if (!packed_dev || !scores_out_dev || !ids_out_dev || W <= 0 || B <= 0 || k <= 0) {
     rf_set_error("rf_merge_shards_packed: bad argument");
     return RF_ERR_INVALID;
   }
-  // shard w = { fp64 score bits [B, k], int64 ids [B, k] }: 2 B k words per shard
-  return rf_launch_merge_shards((const double*)packed_dev, packed_dev + (size_t)B * k, (size_t)2 * B * k, 0, W, 1,
-                                B, k, scores_out_dev, ids_out_dev, (hipStream_t)stream);
-}
-
-extern "C" int rf_merge_shards_group(const int64_t* packed_dev, int W, int L, int B, int k,
-                                     float* scores_out_dev, int64_t* ids_out_dev, void* stream) {
-  if (!packed_dev || !scores_out_dev || !ids_out_dev || W <= 0 || L <= 0 || B <= 0 || k <= 0) {
-    rf_set_error("rf_merge_shards_group: bad argument");
-    return RF_ERR_INVALID;
-  }
-  // packed [W][L][2][B][k]: L batches ("lanes") gathered by ONE collective, merged by one launch
-  return rf_launch_merge_shards((const double*)packed_dev, packed_dev + (size_t)B * k, (size_t)L * 2 * B * k,
-                                (size_t)2 * B * k, W, L, B, k, scores_out_dev, ids_out_dev, (hipStream_t)stream);
+  // shard w = { fp64 score bits [B, k], int64 ids [B, k], uint32 flags [B] (padded to a whole word) }
+  const size_t words = rf_packed_shard_words(B, k);
+  return rf_launch_merge_shards((const double*)packed_dev, packed_dev + (size_t)B * k, words, W, B, k, scores_out_dev,
+                                ids_out_dev, (const uint32_t*)(packed_dev + (size_t)2 * B * k), words * 2, flags_out_dev,
+                                (hipStream_t)stream);
 }
 
 extern "C" int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,

@@ -159,7 +159,6 @@ struct EncWs {
   _Float16* ctx;      // [Mpad, 384]
   _Float16* ff;       // [Mpad, I]
   float* pre;         // [min(Mpad, SM_MAX_TOK), 384] fp32: pre-LayerNorm sums of the small-batch path
-  uint32_t* ln_ctr;   // [SM_MAX_TOK / 64] arrival counters of the small-batch LayerNorm hand-off (zeroed by k_tok_offsets)
 };
 
 static size_t enc_carve(unsigned char* base, int B, int T, int I, EncWs* ws) {
@@ -177,8 +176,7 @@ static size_t enc_carve(unsigned char* base, int B, int T, int I, EncWs* ws) {
   _Float16* ctx = (_Float16*)take(Mpad * HID * 2);
   _Float16* ff = (_Float16*)take(Mpad * (size_t)I * 2);
   float* pre = (float*)take((Mpad < SM_MAX_TOK ? Mpad : (size_t)SM_MAX_TOK) * HID * 4);
-  uint32_t* ln_ctr = (uint32_t*)take((SM_MAX_TOK / 64) * 4);
-  if (ws) *ws = EncWs{tok, x, y, qkv, ctx, ff, pre, ln_ctr};
+  if (ws) *ws = EncWs{tok, x, y, qkv, ctx, ff, pre};
   return off;
 }
 
@@ -194,8 +192,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __global__ void __launch_bounds__(256) k_tok_offsets(const int32_t* __restrict__ lens, int B, int T,
-                                                     int32_t* __restrict__ tok_off, uint32_t* __restrict__ ln_ctr) {
-  if (threadIdx.x < SM_MAX_TOK / 64) ln_ctr[threadIdx.x] = 0u;   // first kernel of every forward
+                                                     int32_t* __restrict__ tok_off) {
   // exclusive scan of clamp(lens, 0, T) by one workgroup
   __shared__ int32_t part[256];
   const int tid = threadIdx.x;
@@ -744,8 +741,7 @@ template <int EPI, int KS>
 __global__ void __launch_bounds__(256) k_linear_small(
     const _Float16* __restrict__ X, const uint4* __restrict__ Wt, const _Float16* __restrict__ bias,
     _Float16* __restrict__ out, float* __restrict__ pre, int N, const int32_t* __restrict__ m_ptr,
-    const _Float16* __restrict__ res, const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
-    float eps, uint32_t* __restrict__ ln_ctr) {
+    const _Float16* __restrict__ res) {
   constexpr int KW = KS / 4;   // k-steps per wave
   __shared__ float red[4][2][16][64];   // [wave][token block][register][lane]: 32 KB
   const int tid = threadIdx.x;
@@ -828,33 +824,12 @@ __global__ void __launch_bounds__(256) k_linear_small(
       if (token < M) *(half4*)(out + toff(token, f, N / 16)) = o;
     }
   }
-  // LayerNorm tail (ln_ctr != nullptr; rf_set_tuning("ln_tail", 1), OFF by default -- measured slower,
-  // see rf_tuning_ln_tail): the workgroup whose fp32 sums complete a 64-token block -- the last of the
-  // N / 32 feature blocks to arrive at that block's counter -- normalises its rows, so the LayerNorm
-  // needs no launch of its own (12 of the 45 launches of a forward).  Hand-off: every thread's stores, an agent-scope
-  // fence, the workgroup barrier, ONE atomic add by thread 0; the workgroup that drew the last ticket
-  // fences again (acquire: the other workgroups' rows may sit in another XCD's L2) and reads.
-  // Same arithmetic as k_ln_rows on the same fp32 sums: bit-identical output.
-  if (EPI == EPI_PRE_LN && ln_ctr != nullptr) {
-    __shared__ uint32_t s_last;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-      const uint32_t t = __hip_atomic_fetch_add(&ln_ctr[blockIdx.y], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (t == gridDim.x - 1u) ? 1u : 0u;
-      if (s_last) __hip_atomic_store(&ln_ctr[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next GEMM
-    }
-    __syncthreads();
-    if (s_last) {
-      __threadfence();
-      const int end = (t0 + SM_TOK < M) ? t0 + SM_TOK : M;
-      for (int tk = t0 + wave; tk < end; tk += 4) ln_row(pre, tk, lane, gamma, beta, eps, out);
-    }
-  }
 }
 
 // LayerNorm of fp32 rows [token][384] -> fp16 tiled activations; one wave per token
-// (rf_set_tuning("ln_tail", 0): the separate-launch form of the small-batch LayerNorm)
+// (the LayerNorm of the small-batch path.  Tried and dropped: the GEMM's last-arriving workgroup
+// normalising the rows behind agent-scope fences and one atomic -- 250 vs 222 us per 12-token
+// encode, the hand-off costs more than the ~5 us dependent launch it removes)
 __global__ void __launch_bounds__(256) k_ln_rows(const float* __restrict__ pre, const int32_t* __restrict__ m_ptr,
                                                  const _Float16* __restrict__ gamma,
                                                  const _Float16* __restrict__ beta, float eps,
@@ -1123,74 +1098,52 @@ __global__ void __launch_bounds__(192) k_pool_norm(const _Float16* __restrict__ 
   }
 }
 
-void* rf_debug_buffer = nullptr;   // rf_debug_set_buffer: clock stamps of the diagnostic runs
-extern "C" int rf_debug_set_buffer(void* dev_ptr) {
-  rf_debug_buffer = dev_ptr;
-  return RF_OK;
-}
-int rf_debug_linear_flags = 0;   // ablation bits of k_linear_dma (rf_set_tuning("linear_dbg", v))
-int rf_debug_epi = 1;   // which k_linear_dma epilogue (0 QKV, 1 FFN1) writes the stamps
-int rf_tuning_ffn2_ntb = 4;   // token blocks per workgroup of the K = 1536 LayerNorm GEMM (2 | 4): 128-token tiles
-                              // halve the weight traffic per token (22.4 vs 21.7 M tokens/s)
-int rf_tuning_k384_ntb = 4;   // the same for the K = 384 direct-load GEMM that is left at large batch (out-proj + LN: +1 %;
-                              // for QKV / FFN1 with linear_dma = 0 the 64-token tiles are faster: 21.1 vs 19.8 M tokens/s)
-int rf_tuning_ln_tail = 0;        // small-batch path: 1 = LayerNorm by the last-arriving workgroup of the GEMM instead of
-                                  // its own launch.  Measured SLOWER (a 12-token query: encode 250 vs 222 us, same box,
-                                  // bit-identical output): the hand-off's two agent-scope fences and the atomic round trip
-                                  // cost more than the ~5 us of a dependent launch they remove.  Kept as an A/B knob.
-int rf_tuning_linear_small = 1;   // B * T <= SM_MAX_TOK: feature-split GEMMs + separate LayerNorm (A/B knob)
-int rf_tuning_linear_dma = 1;   // K = 384 GEMMs with plain epilogues through the LDS-DMA ring (A/B knob)
-
 // ---- forward pass -----------------------------------------------------------------------
 // the LayerNorm-fused GEMMs have only 384 output features (one feature group), so
 // they take 32-token tiles to put twice as many workgroups on the chip
 template <int EPI>
 static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Float16* bias,
                           _Float16* out, int N, int tokens, const int32_t* m_ptr, const _Float16* res,
-                          const _Float16* g, const _Float16* b, float eps, float* pre, uint32_t* ln_ctr, hipStream_t st) {
+                          const _Float16* g, const _Float16* b, float eps, float* pre, hipStream_t st) {
   constexpr int NTB = 2;
   const int tiles = (tokens + 32 * NTB - 1) / (32 * NTB);
-  if (tokens <= SM_MAX_TOK && rf_tuning_linear_small) {
+  if (tokens <= SM_MAX_TOK && rf_knob_linear_small) {
     // small batches: output features spread over the chip (k_linear_small), LayerNorm as its own launch
     const dim3 grid(N / 32, (tokens + SM_TOK - 1) / SM_TOK);
     constexpr int E = (EPI == EPI_BIAS_RES_LN) ? (int)EPI_PRE_LN : (int)EPI;
-    uint32_t* ctr = (EPI == EPI_BIAS_RES_LN && rf_tuning_ln_tail) ? ln_ctr : nullptr;
     if (K == 384)
-      hipLaunchKernelGGL((k_linear_small<E, 24>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res, g, b, eps, ctr);
+      hipLaunchKernelGGL((k_linear_small<E, 24>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res);
     else
-      hipLaunchKernelGGL((k_linear_small<E, 96>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res, g, b, eps, ctr);
-    if (EPI == EPI_BIAS_RES_LN && !ctr)
+      hipLaunchKernelGGL((k_linear_small<E, 96>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res);
+    if (EPI == EPI_BIAS_RES_LN)
       hipLaunchKernelGGL(k_ln_rows, dim3((tokens + 3) / 4), dim3(256), 0, st, pre, m_ptr, g, b, eps, out);
     return;
   }
-  if (K == 384 && EPI != EPI_BIAS_RES_LN && rf_tuning_linear_dma && tokens >= 8192) {
+  if (K == 384 && EPI != EPI_BIAS_RES_LN && rf_knob_linear_dma && tokens >= 8192) {
     const size_t lds = (size_t)LD_SLOTS * LD_FRAGS * RF_FRAG_BYTES + RF_FRAG_BYTES + (size_t)N * 2;
     constexpr int E = (EPI == EPI_BIAS_GELU ? EPI_BIAS_GELU : EPI_BIAS);
     // 256-token workgroups once they still fill the chip (>= 256 of them would need 64 k tokens;
     // from ~48 k the halved weight traffic and per-wave overhead outweigh the idle CUs)
-    const bool wide = rf_tuning_linear_dma == 2 || (rf_tuning_linear_dma == 1 && tokens >= 49152);   // 3: never
-    static size_t attr[2] = {0, 0};
-    if (lds > attr[wide]) {
-      if (wide) (void)hipFuncSetAttribute((const void*)k_linear_dma<E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      else (void)hipFuncSetAttribute((const void*)k_linear_dma<E, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr[wide] = lds;
-    }
-    float* dbgp = (rf_debug_epi == (int)EPI) ? (float*)rf_debug_buffer : nullptr;
+    const bool wide = rf_knob_linear_dma == 2 || (rf_knob_linear_dma == 1 && tokens >= 49152);   // 3: never
+    static rf_lds_attr attr[2];   // per epilogue (template), per form, per device
+    if (wide) (void)rf_ensure_lds(attr[1], (const void*)k_linear_dma<E, 1>, lds);
+    else (void)rf_ensure_lds(attr[0], (const void*)k_linear_dma<E, 0>, lds);
+    float* dbgp = (rf_knob_debug_epi == (int)EPI) ? (float*)rf_debug_buffer : nullptr;
     if (wide)
       hipLaunchKernelGGL((k_linear_dma<E, 1>), dim3((tokens + 2 * LD_TOK - 1) / (2 * LD_TOK)), dim3(LD_WAVES * 64), lds,
-                         st, X, Wt, bias, out, N, m_ptr, dbgp, rf_debug_linear_flags);
+                         st, X, Wt, bias, out, N, m_ptr, dbgp, rf_knob_linear_dbg);
     else
       hipLaunchKernelGGL((k_linear_dma<E, 0>), dim3((tokens + LD_TOK - 1) / LD_TOK), dim3(LD_WAVES * 64), lds, st, X,
-                         Wt, bias, out, N, m_ptr, dbgp, rf_debug_linear_flags);
+                         Wt, bias, out, N, m_ptr, dbgp, rf_knob_linear_dbg);
     return;
   }
-  if (K == 384 && rf_tuning_k384_ntb == 4 && tokens >= 8192)   // 128-token tiles
+  if (K == 384 && rf_knob_k384_ntb == 4 && tokens >= 8192)   // 128-token tiles
     hipLaunchKernelGGL((k_linear<EPI, 4, 24>), dim3((tokens + 127) / 128, N / 384), dim3(256), 0, st, X, K, Wt, bias,
                        out, N, m_ptr, res, g, b, eps);
   else if (K == 384)
     hipLaunchKernelGGL((k_linear<EPI, NTB, 24>), dim3(tiles, N / 384), dim3(256), 0, st, X, K, Wt, bias, out,
                        N, m_ptr, res, g, b, eps);
-  else if (rf_tuning_ffn2_ntb == 4 && tokens >= 8192)   // experiment: 128-token tiles for the K = 1536 GEMM
+  else if (rf_knob_ffn2_ntb == 4 && tokens >= 8192)   // experiment: 128-token tiles for the K = 1536 GEMM
     hipLaunchKernelGGL((k_linear<EPI, 4, 96>), dim3((tokens + 127) / 128, N / 384), dim3(256), 0, st, X, K, Wt, bias,
                        out, N, m_ptr, res, g, b, eps);
   else   // K == 1536 (checked by rf_encoder_create: intermediate == 4 * hidden is the only other K)
@@ -1198,21 +1151,14 @@ static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Floa
                        N, m_ptr, res, g, b, eps);
 }
 
-int rf_tuning_encode_graph = -1;   // small batches through a cached hipGraph (RF_ENCODE_GRAPH=0 / rf_set_tuning to disable)
 static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev, int B, int T,
                           void* out_f16_dev, float* out_f32_dev, void* workspace_dev, hipStream_t st);
 
 // First call with a (shape, buffers) key: plain launches.  Second: the same launch sequence is
 // captured on a private stream, instantiated and replayed on the caller's stream; later calls
 // replay.  Returns RF_ERR_UNSUPPORTED when the caller should use plain launches.
-extern int rf_tuning_generation;   // api.hip: bumped by every rf_set_tuning
 static int encode_graphed(const rf_encoder_t* enc, const int32_t* ids, const int32_t* lens, int B, int T, void* o16,
                           float* o32, void* wsp, hipStream_t st) {
-  if (rf_tuning_encode_graph < 0) {
-    const char* v = getenv("RF_ENCODE_GRAPH");
-    rf_tuning_encode_graph = (v && v[0] == '0') ? 0 : 1;
-    if (!rf_tuning_encode_graph) return RF_ERR_UNSUPPORTED;
-  }
   std::lock_guard<std::mutex> lock(enc->mu);
   // graphs captured under other tuning settings (rf_set_tuning picks kernels) are dropped
   for (size_t i = 0; i < enc->graphs.size();) {
@@ -1285,7 +1231,7 @@ extern "C" int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const 
     return RF_ERR_CAPACITY;
   }
   hipStream_t st = (hipStream_t)stream;
-  if ((size_t)B * T <= SM_MAX_TOK && rf_tuning_encode_graph) {
+  if ((size_t)B * T <= SM_MAX_TOK && rf_knob_encode_graph) {
     const int rc = encode_graphed(enc, ids_dev, lens_dev, B, T, out_f16_dev, out_f32_dev, workspace_dev, st);
     if (rc != RF_ERR_UNSUPPORTED) return rc;   // RF_ERR_UNSUPPORTED here = "take the plain path"
   }
@@ -1302,7 +1248,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
   const int tiles = B * T;   // token slots; launch_linear turns them into tiles
   const int32_t* m_ptr = ws.tok_off + B;
 
-  hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off, ws.ln_ctr);
+  hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off);
   {
     int64_t waves = (int64_t)B * T;
     int grid = (int)((waves + 3) / 4);
@@ -1313,19 +1259,11 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
                        (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
   }
   const size_t attn_lds = (size_t)T * 2 * HEAD_DIM * 2;
-  static size_t attn_attr = 0, mfma_attr = 0;
-  if (attn_lds > attn_attr) {
-    RF_HIP(hipFuncSetAttribute((const void*)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)attn_lds));
-    attn_attr = attn_lds;
-  }
+  static rf_lds_attr attn_attr, mfma_attr;
+  if (T > 32 * ATT_MAX_KB) RF_HIP(rf_ensure_lds(attn_attr, (const void*)k_attention, attn_lds));
   const int tpad_max = (T + 31) / 32 * 32;
   const size_t mfma_lds = ATT_HEADS * ((size_t)tpad_max * 80 + (size_t)32 * (tpad_max + 4) * 2);  // 74 KB at T = 256
-  if (T <= 32 * ATT_MAX_KB && mfma_lds > mfma_attr) {
-    RF_HIP(hipFuncSetAttribute((const void*)k_attention_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)mfma_lds));
-    mfma_attr = mfma_lds;
-  }
+  if (T <= 32 * ATT_MAX_KB) RF_HIP(rf_ensure_lds(mfma_attr, (const void*)k_attention_mfma, mfma_lds));
   _Float16* x = ws.x;
   _Float16* y = ws.y;
   for (int l = 0; l < L; ++l) {
@@ -1334,7 +1272,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
     const uint4* ff1_t = enc->ff1_t + (size_t)l * I * HID / 8;
     const uint4* ff2_t = enc->ff2_t + (size_t)l * HID * I / 8;
     launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
-                            3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, ws.ln_ctr, st);
+                            3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
     if (T <= 32 * ATT_MAX_KB)
       hipLaunchKernelGGL(k_attention_mfma, dim3(B, c.heads / ATT_HEADS), dim3(256), mfma_lds, st, ws.qkv,
                          ws.tok_off, ws.ctx);
@@ -1343,12 +1281,12 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
                          ws.ctx);
     launch_linear<EPI_BIAS_RES_LN>(ws.ctx, HID, ao_t, (const _Float16*)w.ao_b + (size_t)l * HID, y, HID,
                                    tiles, m_ptr, x, (const _Float16*)w.ln1_g + (size_t)l * HID,
-                                   (const _Float16*)w.ln1_b + (size_t)l * HID, c.ln_eps, ws.pre, ws.ln_ctr, st);
+                                   (const _Float16*)w.ln1_b + (size_t)l * HID, c.ln_eps, ws.pre, st);
     launch_linear<EPI_BIAS_GELU>(y, HID, ff1_t, (const _Float16*)w.ff1_b + (size_t)l * I, ws.ff, I,
-                                 tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, ws.ln_ctr, st);
+                                 tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
     launch_linear<EPI_BIAS_RES_LN>(ws.ff, I, ff2_t, (const _Float16*)w.ff2_b + (size_t)l * HID, x, HID,
                                    tiles, m_ptr, y, (const _Float16*)w.ln2_g + (size_t)l * HID,
-                                   (const _Float16*)w.ln2_b + (size_t)l * HID, c.ln_eps, ws.pre, ws.ln_ctr, st);
+                                   (const _Float16*)w.ln2_b + (size_t)l * HID, c.ln_eps, ws.pre, st);
   }
   hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(192), 0, st, x, ws.tok_off, (_Float16*)out_f16_dev,
                      out_f32_dev);

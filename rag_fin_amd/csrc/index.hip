@@ -17,7 +17,7 @@ void rf_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* rf_last_error(void) { return g_err; }
-extern "C" int rf_version(void) { return 100; }
+extern "C" int rf_version(void) { return 200; }
 
 extern "C" int rf_device_check(int device) {
   int n = 0;
@@ -91,24 +91,11 @@ extern "C" int rf_index_create(rf_index_t** out, int dim, int64_t capacity_rows,
     RF_HIP(hipGetDeviceProperties(&prop, device));
     ix->num_cus = prop.multiProcessorCount;
   }
-  for (int i = 0; i < 8; ++i) ix->ws_clean[i] = nullptr;
-  ix->ws_clean_next = 0;
   *out = ix;
   return RF_OK;
 }
 
-static void drop_graphs(rf_index* ix) {
-  std::lock_guard<std::mutex> lock(ix->graph_mu);
-  for (auto& g : ix->graphs)
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  ix->graphs.clear();
-}
-
 extern "C" int rf_index_destroy(rf_index_t* ix) {
-  if (ix) {
-    drop_graphs(ix);
-    if (ix->cap_stream) (void)hipStreamDestroy(ix->cap_stream);
-  }
   delete ix;
   return RF_OK;
 }
@@ -223,7 +210,6 @@ extern "C" int rf_index_reset(rf_index_t* ix, void* stream) {
     rf_set_error("rf_index_reset: null index");
     return RF_ERR_INVALID;
   }
-  drop_graphs(ix);
   ix->size = 0;
   RF_HIP(hipMemsetAsync(ix->max_norm2, 0, 256, (hipStream_t)stream));
   return RF_OK;

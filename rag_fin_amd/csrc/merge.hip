@@ -177,8 +177,7 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
     int64_t id_base, const uint32_t* __restrict__ cand_cnt, const uint2* __restrict__ cand,
     uint32_t cap, const float* __restrict__ eps_in, float* __restrict__ scores,
     int64_t* __restrict__ ids, double* __restrict__ exact, uint32_t* __restrict__ flags,
-    uint32_t* __restrict__ cand_cnt_rw, uint32_t* __restrict__ gmax, uint32_t* __restrict__ bar,
-    uint32_t n_rows) {
+    uint32_t* __restrict__ cand_cnt_rw, uint32_t n_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned long long* skeys = (unsigned long long*)lds;                       // [1024]
   unsigned long long* wtop = skeys + MERGE_RANK_MAX;                          // [4][RF_MAX_K]
@@ -217,8 +216,9 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
 #pragma unroll
     for (int t = 1; t < RF_CAND_SHARDS; ++t) s += g >= off[t] ? 1 : 0;
     uint2 e = lists[(size_t)s * cap + (g - off[s])];
-    // a row id past the corpus can only come from a workspace whose control block was
-    // not clean; never let it reach the row gather -- make it the worst candidate and flag
+    // a row id past the corpus cannot come from the sweep (k_threshold zeroes the counters of
+    // every search); should one appear (a caller sharing one workspace between concurrent
+    // searches), never let it reach the row gather -- make it the worst candidate and flag
     if (e.x >= n_rows) {
       e.x = 0u;
       e.y = 0xFF800000u;  // -inf
@@ -381,11 +381,10 @@ __global__ void __launch_bounds__(MERGE_THREADS) k_merge(
   }
   if (flags && __syncthreads_or(bad_row ? 1 : 0)) fl |= RF_FLAG_CAND_OVERFLOW;
   if (tid == 0 && flags) flags[qi] = fl;
-  // leave the control block zero for the next search on this workspace (every
-  // thread of this workgroup read its counters before the barriers above)
+  // leave the counters zero (every thread of this workgroup read them before the barriers
+  // above); k_threshold zeroes them again at the start of every search, so a search never
+  // depends on what an earlier one -- or an error return mid-pipeline -- left behind
   if (tid < RF_CAND_SHARDS) cand_cnt_rw[qi * RF_CAND_SHARDS + tid] = 0u;
-  if (tid < RF_MAX_K) gmax[qi * RF_MAX_K + tid] = 0u;
-  if (qi == 0 && tid < 2) bar[tid] = 0u;
 }
 // ---- exhaustive exact path ----------------------------------------------------------
 // Workgroup-level running top-k list (sorted, in LDS) updated 256 entries at a
@@ -502,15 +501,23 @@ __global__ void __launch_bounds__(EX_THREADS) k_exhaustive_final(
 // in [W][B][k] (exact fp64, global id) -> out [B][k].  Ids are global and unique,
 // so ranking by (score desc, id asc) reproduces the single-device order bit for bit.
 __global__ void __launch_bounds__(EX_THREADS) k_merge_shards(
-    const double* __restrict__ in_s, const int64_t* __restrict__ in_r, size_t sstride, size_t lstride,
-    int W, int B, int k, float* __restrict__ scores, int64_t* __restrict__ ids) {
-  // entry (shard w, lane l = blockIdx.y, query qi, rank j) sits at w * sstride + l * lstride + qi * k + j
-  // in both arrays; outputs are [lane][B][k]
+    const double* __restrict__ in_s, const int64_t* __restrict__ in_r, size_t sstride,
+    int W, int B, int k, float* __restrict__ scores, int64_t* __restrict__ ids,
+    const uint32_t* __restrict__ flags_in, size_t fstride, uint32_t* __restrict__ flags_out) {
+  // entry (shard w, query qi, rank j) sits at w * sstride + qi * k + j in both arrays; shard w's
+  // per-query exactness flags (optional) at flags_in[w * fstride + qi]: the merged answer of a
+  // query is proven exact only if EVERY shard's local answer was, so the output flag is their OR
   const int qi = blockIdx.x;
   const int tid = threadIdx.x;
   const int m = W * k;
-  const size_t qoff = (size_t)blockIdx.y * lstride + (size_t)qi * k;
-  const size_t ooff = ((size_t)blockIdx.y * B + qi) * k;
+  const size_t qoff = (size_t)qi * k;
+  const size_t ooff = (size_t)qi * k;
+  if (flags_out && tid == 0) {
+    uint32_t f = 0u;
+    if (flags_in)
+      for (int w = 0; w < W; ++w) f |= flags_in[(size_t)w * fstride + qi];
+    flags_out[qi] = f;
+  }
   for (int i = tid; i < m; i += EX_THREADS) {
     const int w = i / k, j = i % k;
     const size_t src = (size_t)w * sstride + qoff + j;
@@ -557,16 +564,11 @@ int rf_launch_merge(const rf_index* ix, const void* q, int B, int k, int64_t id_
                     const rf_workspace& ws, float* scores, int64_t* ids, double* exact,
                     uint32_t* flags, hipStream_t st) {
   const size_t lds = merge_lds_bytes(ix->dim);
-  static size_t lds_attr = 0;
-  if (lds > lds_attr) {
-    RF_HIP(hipFuncSetAttribute((const void*)k_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    lds_attr = lds;
-  }
+  static rf_lds_attr lds_attr;
+  RF_HIP(rf_ensure_lds(lds_attr, (const void*)k_merge, lds));
   hipLaunchKernelGGL(k_merge, dim3(B), dim3(MERGE_THREADS), lds, st, (const _Float16*)q, ix->dim,
                      ix->KS, ix->tiles, k, id_base, ws.cand_cnt, ws.cand, (uint32_t)RF_SHARD_CAP,
-                     ws.eps, scores, ids, exact, flags, ws.cand_cnt, ws.gmax, ws.bar,
-                     (uint32_t)ix->size);
+                     ws.eps, scores, ids, exact, flags, ws.cand_cnt, (uint32_t)ix->size);
   RF_HIP(hipGetLastError());
   return RF_OK;
 }
@@ -585,10 +587,11 @@ int rf_launch_exhaustive(const rf_index* ix, const void* q, int B, int k, int64_
   return RF_OK;
 }
 
-int rf_launch_merge_shards(const double* exact, const int64_t* ids, size_t shard_stride, size_t lane_stride,
-                           int W, int L, int B, int k, float* scores_out, int64_t* ids_out, hipStream_t st) {
-  hipLaunchKernelGGL(k_merge_shards, dim3(B, L), dim3(EX_THREADS), 0, st, exact, ids, shard_stride, lane_stride, W,
-                     B, k, scores_out, ids_out);
+int rf_launch_merge_shards(const double* exact, const int64_t* ids, size_t shard_stride, int W, int B, int k,
+                           float* scores_out, int64_t* ids_out, const uint32_t* flags_in, size_t flag_stride,
+                           uint32_t* flags_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_merge_shards, dim3(B), dim3(EX_THREADS), 0, st, exact, ids, shard_stride, W, B, k,
+                     scores_out, ids_out, flags_in, flag_stride, flags_out);
   RF_HIP(hipGetLastError());
   return RF_OK;
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "../../include/ragfin.h"
@@ -32,26 +33,60 @@ struct rf_index {
   uint4* tiles;        // device: capacity_blocks * KS * 64 uint4
   uint32_t* max_norm2; // device: bits of max squared row norm (float >= 0)
   size_t storage_bytes;
-  int num_cus;         // compute units of `device` (sizes the co-resident fused grid)
-  mutable const void* ws_clean[8];  // workspaces whose control block this index has zeroed
-  mutable int ws_clean_next;
-  // rf_search calls that repeat with the same buffers (a serving lane, a shard's step) replay a
-  // cached hipGraph of their 4-5 launches: a launch costs ~4.5 us of host time, which -- not the
-  // kernels -- bounds the step on small corpora / shards
-  struct Graph {
-    const void* q;
-    int B, k;
-    int64_t id_base, size;
-    void *scores, *ids, *exact, *flags, *ws;
-    int tuning_gen;
-    hipGraphExec_t exec;   // nullptr: key seen once (that plain run also zeroes the workspace, sets attributes)
-    bool dead;
-  };
-  mutable std::vector<Graph> graphs;
-  mutable hipStream_t cap_stream = nullptr;
-  mutable std::mutex graph_mu;
+  int num_cus;         // compute units of `device`
 };
-extern int rf_tuning_generation;   // bumped by rf_set_tuning: cached graphs of older settings are not replayed
+// An index is immutable during searches (no mutable host state: any number of threads may
+// search one index concurrently, each with its own workspace and stream); rf_index_add_f16 /
+// rf_index_reset must not run concurrently with a search (include/ragfin.h, "Threading").
+
+// ---- tuning knobs ------------------------------------------------------------------------
+// The shipped library has NO run-time tuning surface: every knob below is a compile-time
+// constant.  Built with -DRF_EXPERIMENTS (python -m rag_fin_amd.build --experiments ->
+// libragfin_hip_exp.so, used by tools/ only) the same names are process-wide ints set through
+// rf_set_tuning, for A/B runs in one process.
+#ifdef RF_EXPERIMENTS
+#define RF_KNOB(name, dflt) extern int name;
+#else
+#define RF_KNOB(name, dflt) static constexpr int name = dflt;
+#endif
+RF_KNOB(rf_knob_ring24, 8)             // register-ring depth (fragments) of the dim-384 emit sweep: 6 | 8 | 12 | 24
+RF_KNOB(rf_knob_emit_wgs_per_cu, 0)    // emit grid = CUs x this (0 = default for the dim)
+RF_KNOB(rf_knob_sample_bpw, 2)         // sample blocks per wave
+RF_KNOB(rf_knob_wide_sample_pairs, 4)  // wide sample pass: block pairs per workgroup, at most
+RF_KNOB(rf_knob_wide_dbg, 0)           // wide sweep diagnostic bits (clock stamps, cached-KiB ablation)
+RF_KNOB(rf_knob_linear_dma, 1)         // encoder: K = 384 plain-epilogue GEMMs through the LDS-DMA ring (0 off, 1 auto, 2 always 256-token, 3 never 256-token)
+RF_KNOB(rf_knob_linear_small, 1)       // encoder: feature-split GEMMs + separate LayerNorm at <= 1024 token slots
+RF_KNOB(rf_knob_k384_ntb, 4)           // encoder: token blocks per workgroup of the K = 384 LayerNorm GEMM at large batch
+RF_KNOB(rf_knob_ffn2_ntb, 4)           // encoder: the same for the K = 1536 LayerNorm GEMM
+RF_KNOB(rf_knob_encode_graph, 1)       // encoder: query-sized forwards replay a cached hipGraph
+RF_KNOB(rf_knob_linear_dbg, 0)         // encoder: k_linear_dma ablation bits (results wrong)
+RF_KNOB(rf_knob_debug_epi, 1)          // encoder: which k_linear_dma epilogue writes clock stamps
+#undef RF_KNOB
+#ifdef RF_EXPERIMENTS
+extern int rf_tuning_generation;   // bumped by rf_set_tuning: cached encode graphs of older settings are not replayed
+extern void* rf_debug_buffer;      // rf_debug_set_buffer: clock stamps of the diagnostic runs
+#else
+static constexpr int rf_tuning_generation = 0;
+static constexpr void* rf_debug_buffer = nullptr;
+#endif
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: cache what has
+// been set per device, not per process (a second index / encoder on another GPU of the same
+// process must get the attribute too).  Racing first calls both set it: idempotent.
+#define RF_MAX_DEVICES 64
+struct rf_lds_attr {
+  std::atomic<uint32_t> bytes[RF_MAX_DEVICES];
+};
+static inline hipError_t rf_ensure_lds(rf_lds_attr& a, const void* fn, size_t lds) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= RF_MAX_DEVICES) return hipErrorInvalidDevice;
+  if (a.bytes[dev].load(std::memory_order_relaxed) >= lds) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) a.bytes[dev].store((uint32_t)lds, std::memory_order_relaxed);
+  return e;
+}
 
 // queries per wide sweep (scan_wide.hip); every per-query workspace array is sized for it
 #define RF_QWIDE 256
@@ -72,9 +107,6 @@ struct rf_workspace {
   float* eps;          // [64]
   uint32_t* cand_cnt;  // [64][RF_CAND_SHARDS]
   float* pmax;         // [64][RF_SAMPLE_WGS]
-  uint32_t* gmax;      // [64][RF_MAX_K] fused scan: ordered-uint group maxima (zero = empty)
-  uint32_t* bar;       // [16] fused scan: [0] arrivals, [1] give-up marker
-  size_t ctl_bytes;    // bytes from the workspace base that must be zero before a search
   uint2* cand;         // [64][RF_CAND_SHARDS][RF_SHARD_CAP]  {row, score bits}
   // exhaustive path
   double* ex_score;    // [RF_EX_LISTS][RF_MAX_K]
@@ -109,9 +141,6 @@ int rf_wide_supported(const rf_index* ix);
 int rf_launch_wide_sample(const rf_index* ix, const void* q, int B, const rf_workspace& ws, int* P_out,
                           hipStream_t st);
 int rf_launch_wide_emit(const rf_index* ix, const void* q, int B, const rf_workspace& ws, hipStream_t st);
-// scan_fused.hip
-int rf_launch_fused(const rf_index* ix, const void* q, int B, int JB, int k, const rf_workspace& ws,
-                    hipStream_t st);
 // merge.hip
 int rf_launch_threshold(const rf_index* ix, const void* q, int B, int k, int P,
                         const rf_workspace& ws, hipStream_t st);
@@ -121,8 +150,9 @@ int rf_launch_merge(const rf_index* ix, const void* q, int B, int k, int64_t id_
 int rf_launch_exhaustive(const rf_index* ix, const void* q, int B, int k, int64_t id_base,
                          const rf_workspace& ws, float* scores, int64_t* ids, double* exact,
                          const double* after_s, const int64_t* after_r, hipStream_t st);
-int rf_launch_merge_shards(const double* exact, const int64_t* ids, size_t shard_stride, size_t lane_stride,
-                           int W, int L, int B, int k, float* scores_out, int64_t* ids_out, hipStream_t st);
+int rf_launch_merge_shards(const double* exact, const int64_t* ids, size_t shard_stride, int W, int B, int k,
+                           float* scores_out, int64_t* ids_out, const uint32_t* flags_in, size_t flag_stride,
+                           uint32_t* flags_out, hipStream_t st);
 
 // order-preserving map float -> uint32 (larger float <=> larger uint)
 __host__ __device__ inline uint32_t rf_f2ord(float f) {

@@ -169,110 +169,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_scan(ScanParams p) {
   }
 }
 
-// ---- emit sweep with the queries in registers (dim 384, 33..64 queries; EXPERIMENT) --------
-// k_scan re-reads its query fragments from LDS at every k-step (two ds_read_b128 per MFMA
-// pair), and the 64-query sweep is ~4 % slower than the 32-query one (120.6 vs 115.6 us at
-// 1M x 384, where a bare streaming read of the same bytes takes 111.6 us).  This form tests
-// whether that LDS traffic is the cost: a wave keeps all 64 queries as 48 B-operand fragments
-// in the accumulator half of its register file (one wave per SIMD, the whole 512-register
-// file), streams its corpus blocks through a full-block register ring and touches LDS only to
-// stage the rare hits -- no barrier, no LDS in the loop.  Measured: 122.0 us against 120.2 us
-// for k_scan in the same process, i.e. the LDS reads are NOT what the second MFMA per
-// fragment costs (the sweep slows with the matrix work itself: the chip trades clock and
-// fabric rate for MFMA power).  Kept behind rf_set_tuning("qreg", 1) / RF_QREG=1, parity-tested.
-template <int MODE>
-__global__ void __launch_bounds__(256, 1) k_scan_qreg(ScanParams p) {
-  constexpr int KS = 24, R = 24, JB = 2, WAVES = 4;
-  __shared__ __attribute__((aligned(16))) uint32_t stage_lds[3 * WAVES * SCAP];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5;
-
-  const uint32_t W = gridDim.x * WAVES;
-  const uint32_t gw = blockIdx.x * WAVES + wave;
-  const uint32_t cnt = (p.n_work > gw) ? (p.n_work - gw + W - 1) / W : 0u;
-  if (cnt == 0) return;   // no barrier anywhere in this kernel
-
-  u32x4 ring[R];
-  {
-    const uint4* src = p.corpus + (size_t)gw * p.bstride * (KS * 64) + lane;
-#pragma unroll
-    for (int s = 0; s < R; ++s) ring[s] = ld_frag(src + s * 64);
-  }
-  u32x4 qf[JB][KS];
-  float th[JB], pm[JB];
-#pragma unroll
-  for (int jb = 0; jb < JB; ++jb) {
-    const int qi = jb * 32 + c;
-    const int qc = qi < p.B ? qi : p.B - 1;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
-      qf[jb][kk] = *(const u32x4*)(p.q + (size_t)qc * (KS * 16) + kk * 16 + h * 8);
-    pm[jb] = -INFINITY;
-    th[jb] = (MODE == MODE_EMIT) ? p.thr[qc] : 0.f;
-    if (qi >= p.B) th[jb] = INFINITY;
-  }
-#pragma unroll
-  for (int jb = 0; jb < JB; ++jb) {
-    const int qi = jb * 32 + c;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      u32x4 v = qf[jb][kk];
-      if (qi >= p.B) v = u32x4{0u, 0u, 0u, 0u};
-      asm volatile("" : "+a"(v));   // resident in the accumulator half (MFMA reads B from either)
-      qf[jb][kk] = v;
-    }
-  }
-  EmitState es;
-  es.cnt = 0;
-  es.q_base = 0;
-  es.s_row = stage_lds + wave * SCAP;
-  es.s_score = (float*)(stage_lds + WAVES * SCAP) + wave * SCAP;
-  es.s_q = stage_lds + 2 * WAVES * SCAP + wave * SCAP;
-
-  uint32_t w = gw;
-  for (uint32_t i = 0; i < cnt; ++i, w += W) {
-    const uint32_t b = w * p.bstride;
-    // the last block re-arms from itself (loads discarded): every load unconditional
-    const uint32_t bn = (i + 1 < cnt) ? b + W * p.bstride : b;
-    const uint4* nxt = p.corpus + (size_t)bn * (KS * 64) + lane;
-    f32x16 acc[JB];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      const half8 a = __builtin_bit_cast(half8, ring[kk]);
-#pragma unroll
-      for (int jb = 0; jb < JB; ++jb) {
-        if (kk == 0) {
-          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, qf[jb][kk]), z, 0, 0, 0);
-        } else {
-          acc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, qf[jb][kk]), acc[jb], 0, 0, 0);
-        }
-      }
-      ring[kk] = ld_frag(nxt + kk * 64);
-    }
-    const uint32_t row0 = b * 32u;
-    if (MODE == MODE_SAMPLE) {
-      if (row0 + 32u > p.n_rows) {
-#pragma unroll
-        for (int jb = 0; jb < JB; ++jb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (row0 + acc_row(r, h) >= p.n_rows) acc[jb][r] = -INFINITY;
-      }
-#pragma unroll
-      for (int jb = 0; jb < JB; ++jb) pm[jb] = fmaxf(pm[jb], max16(acc[jb]));
-    } else {
-      bool hit = false;
-#pragma unroll
-      for (int jb = 0; jb < JB; ++jb) hit |= (max16(acc[jb]) >= th[jb]);
-      if (__ballot(hit) != 0ull) emit_slow<JB>(acc, th, row0, lane, es, p);
-    }
-  }
-  if (MODE == MODE_EMIT && es.cnt > 0) emit_flush(es, p, lane);
-}
-
 // ---- raw score dump (test hook) ---------------------------------------------
 template <int KS>
 __global__ void __launch_bounds__(64) k_debug_scores(const uint4* corpus, const _Float16* q, int B,
@@ -308,69 +204,47 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t st) {
   if (MODE == MODE_EMIT) lds += (size_t)3 * WAVES * SCAP * 4;
   else lds += (size_t)WAVES * 2 * JB * 32 * 4;
   auto kern = k_scan<KS, R, JB, WAVES, MODE>;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    RF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    attr_done = true;
-  }
+  static rf_lds_attr attr;  // per instantiation, per device
+  RF_HIP(rf_ensure_lds(attr, (const void*)kern, lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, p);
   RF_HIP(hipGetLastError());
   return RF_OK;
 }
 
-// ---- tuning knobs (rf_set_tuning / environment at first use) ---------------------------
-extern int rf_tuning_fused;  // api.hip
-extern int rf_tuning_ffn2_ntb, rf_tuning_k384_ntb, rf_tuning_encode_graph;
-extern int rf_tuning_ln_tail, rf_tuning_linear_dma, rf_tuning_linear_small, rf_debug_epi, rf_debug_linear_flags;   // encoder.hip
-extern int rf_tuning_wide_variant, rf_tuning_wide_nt, rf_tuning_wide_dbg, rf_tuning_wide_sample_pairs;  // scan_wide.hip
-struct ScanTuning {
-  int ring24;           // register-ring depth (fragments) of the dim-384 kernels: 6 | 8 | 12 | 24
-  int emit_wgs_per_cu;  // emit grid = CUs x this (0 = default for the dim)
-  int sample_bpw;       // sample blocks per wave
-  int qreg;             // dim 384, 33..64 queries: emit sweep with the queries in registers (k_scan_qreg)
-};
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-static ScanTuning& tuning() {
-  static ScanTuning t = {env_int("RF_RING24", 8), env_int("RF_EMIT_WGS_PER_CU", 0),
-                         env_int("RF_SAMPLE_BPW", 2), env_int("RF_QREG", 0)};
-  return t;
-}
-extern int rf_tuning_search_graph;   // api.hip
-extern "C" int rf_set_tuning(const char* key, int value) {
-  ScanTuning& t = tuning();
-  if (!key) return RF_ERR_INVALID;
-  ++rf_tuning_generation;   // cached search graphs were captured under the old settings
-  if (!strcmp(key, "search_graph") && (value == 0 || value == 1)) {
-    rf_tuning_search_graph = value;
-    return RF_OK;
-  }
-  if (!strcmp(key, "ring24") && (value == 6 || value == 8 || value == 12 || value == 24)) t.ring24 = value;
-  else if (!strcmp(key, "emit_wgs_per_cu") && value >= 0 && value <= 4) t.emit_wgs_per_cu = value;
-  else if (!strcmp(key, "sample_bpw") && value >= 1 && value <= 8) t.sample_bpw = value;
-  else if (!strcmp(key, "qreg") && (value == 0 || value == 1)) t.qreg = value;
-  else if (!strcmp(key, "linear_dma") && value >= 0 && value <= 3) rf_tuning_linear_dma = value;
-  else if (!strcmp(key, "encode_graph") && (value == 0 || value == 1)) rf_tuning_encode_graph = value;
-  else if (!strcmp(key, "k384_ntb") && (value == 2 || value == 4)) rf_tuning_k384_ntb = value;
-  else if (!strcmp(key, "ffn2_ntb") && (value == 2 || value == 4)) rf_tuning_ffn2_ntb = value;
-  else if (!strcmp(key, "ln_tail") && (value == 0 || value == 1)) rf_tuning_ln_tail = value;
-  else if (!strcmp(key, "linear_small") && (value == 0 || value == 1)) rf_tuning_linear_small = value;
-  else if (!strcmp(key, "linear_dbg") && value >= 0 && value <= 15) rf_debug_linear_flags = value;
-  else if (!strcmp(key, "debug_epi") && (value == 0 || value == 1)) rf_debug_epi = value;
-  else if (!strcmp(key, "fused") && (value == 0 || value == 1)) rf_tuning_fused = value;
-  else if (!strcmp(key, "wide_variant") && value >= 0 && value <= 3) rf_tuning_wide_variant = value;
-  else if (!strcmp(key, "wide_nt") && (value == 0 || value == 1)) rf_tuning_wide_nt = value;
-  else if (!strcmp(key, "wide_sample_pairs") && value >= 1 && value <= 8) rf_tuning_wide_sample_pairs = value;
-  else if (!strcmp(key, "wide_dbg") && value >= 0 && value <= 63) rf_tuning_wide_dbg = value;
-  else {
-    rf_set_error("rf_set_tuning: unknown key or bad value (%s = %d)", key, value);
-    return RF_ERR_INVALID;
-  }
+// ---- tuning knobs: compile-time constants in the shipped library (rf_internal.h); the
+// experiments build (tools/ only) makes them process-wide ints behind rf_set_tuning -----------
+#ifdef RF_EXPERIMENTS
+int rf_knob_ring24 = 8, rf_knob_emit_wgs_per_cu = 0, rf_knob_sample_bpw = 2;
+int rf_knob_wide_sample_pairs = 4, rf_knob_wide_dbg = 0;
+int rf_knob_linear_dma = 1, rf_knob_linear_small = 1, rf_knob_k384_ntb = 4, rf_knob_ffn2_ntb = 4;
+int rf_knob_encode_graph = 1, rf_knob_linear_dbg = 0, rf_knob_debug_epi = 1;
+int rf_tuning_generation = 0;
+void* rf_debug_buffer = nullptr;
+extern "C" int rf_debug_set_buffer(void* dev_ptr) {
+  rf_debug_buffer = dev_ptr;
   return RF_OK;
 }
+extern "C" int rf_set_tuning(const char* key, int value) {
+  if (!key) return RF_ERR_INVALID;
+  ++rf_tuning_generation;   // cached encode graphs were captured under the old settings
+  struct K { const char* name; int* var; int lo, hi; };
+  const K keys[] = {{"ring24", &rf_knob_ring24, 6, 24}, {"emit_wgs_per_cu", &rf_knob_emit_wgs_per_cu, 0, 4},
+                    {"sample_bpw", &rf_knob_sample_bpw, 1, 8}, {"wide_sample_pairs", &rf_knob_wide_sample_pairs, 1, 8},
+                    {"wide_dbg", &rf_knob_wide_dbg, 0, 63}, {"linear_dma", &rf_knob_linear_dma, 0, 3},
+                    {"linear_small", &rf_knob_linear_small, 0, 1}, {"k384_ntb", &rf_knob_k384_ntb, 2, 4},
+                    {"ffn2_ntb", &rf_knob_ffn2_ntb, 2, 4}, {"encode_graph", &rf_knob_encode_graph, 0, 1},
+                    {"linear_dbg", &rf_knob_linear_dbg, 0, 15}, {"debug_epi", &rf_knob_debug_epi, 0, 1}};
+  for (const K& k : keys)
+    if (!strcmp(key, k.name) && value >= k.lo && value <= k.hi) {
+      if (k.var == &rf_knob_ring24 && value != 6 && value != 8 && value != 12 && value != 24) break;
+      if ((k.var == &rf_knob_k384_ntb || k.var == &rf_knob_ffn2_ntb) && value == 3) break;
+      *k.var = value;
+      return RF_OK;
+    }
+  rf_set_error("rf_set_tuning: unknown key or bad value (%s = %d)", key, value);
+  return RF_ERR_INVALID;
+}
+#endif
 
 template <int MODE>
 static int dispatch_scan(int KS, int JB, const ScanParams& p, int grid4, int grid8,
@@ -386,14 +260,16 @@ static int dispatch_scan(int KS, int JB, const ScanParams& p, int grid4, int gri
   if (KS == 24 && MODE == MODE_EMIT) {
     // short sweeps (a few blocks per wave: shards of a strong-scaled job, BASELINE configs[1]) are
     // latency-bound like the sample pass and prefer the full-block ring too: 21.7 vs 23.3 us at 100 k rows
-    const int ring = (p.n_work < 6u * 4u * (uint32_t)grid4) ? 24 : tuning().ring24;
+    const int ring = (p.n_work < 6u * 4u * (uint32_t)grid4) ? 24 : rf_knob_ring24;
     switch (ring) {
-      case 6:
-        return JB == 1 ? launch_scan<24, 6, 1, 4, MODE>(p, grid4, st) : launch_scan<24, 6, 2, 4, MODE>(p, grid4, st);
       case 8:
         return JB == 1 ? launch_scan<24, 8, 1, 4, MODE>(p, grid4, st) : launch_scan<24, 8, 2, 4, MODE>(p, grid4, st);
+#ifdef RF_EXPERIMENTS
+      case 6:
+        return JB == 1 ? launch_scan<24, 6, 1, 4, MODE>(p, grid4, st) : launch_scan<24, 6, 2, 4, MODE>(p, grid4, st);
       case 12:
         return JB == 1 ? launch_scan<24, 12, 1, 4, MODE>(p, grid4, st) : launch_scan<24, 12, 2, 4, MODE>(p, grid4, st);
+#endif
       default:
         break;
     }
@@ -440,7 +316,7 @@ int rf_launch_sample(const rf_index* ix, const void* q, int B, int JB, const rf_
   // stay ~16 k whatever N is, and a small corpus does not pay a sample pass as long as
   // its scan.  At least 64 workgroups (partitions) so the k-th largest exists for
   // k <= 64, at most RF_SAMPLE_WGS workgroups x SAMPLE_BPW blocks per wave.
-  const int SAMPLE_BPW = tuning().sample_bpw;
+  const int SAMPLE_BPW = rf_knob_sample_bpw;
   uint32_t n_work = nblk / 16;
   const uint32_t lo = 64u * WAVES, hi = (uint32_t)RF_SAMPLE_WGS * WAVES * SAMPLE_BPW;
   if (n_work < lo) n_work = lo;
@@ -470,7 +346,7 @@ int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_wo
   const int KS = ix->KS;
   const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
   const int WAVES = waves_per_wg(KS);
-  const int wgs_env = tuning().emit_wgs_per_cu;
+  const int wgs_env = rf_knob_emit_wgs_per_cu;
   int grid = ix->num_cus * (wgs_env > 0 ? wgs_env : wgs_per_cu(KS));
   const uint32_t need = (nblk + WAVES - 1) / WAVES;
   if ((uint32_t)grid > need) grid = (int)need;
@@ -486,15 +362,6 @@ int rf_launch_emit(const rf_index* ix, const void* q, int B, int JB, const rf_wo
   p.cand_cnt = ws.cand_cnt;
   p.cand = ws.cand;
   p.cap = RF_SHARD_CAP;
-  if (KS == 24 && JB == 2 && tuning().qreg) {
-    // queries in registers: one 4-wave workgroup per CU (one wave per SIMD)
-    int g = ix->num_cus;
-    const uint32_t need4 = (nblk + 3) / 4;
-    if ((uint32_t)g > need4) g = (int)need4;
-    hipLaunchKernelGGL(k_scan_qreg<MODE_EMIT>, dim3(g), dim3(256), 0, st, p);
-    RF_HIP(hipGetLastError());
-    return RF_OK;
-  }
   return dispatch_scan<MODE_EMIT>(KS, JB, p, grid, grid, st);
 }
 

@@ -22,9 +22,6 @@
 #include <stdlib.h>
 
 #define WIDE_KS 24
-#define WIDE_WAVES 8
-#define WIDE_DEPTH 3   // blocks in flight per wave (register ring)
-#define WIDE_PIECES (WIDE_KS / WIDE_WAVES)
 
 struct WideParams {
   const uint4* corpus;
@@ -39,230 +36,27 @@ struct WideParams {
   uint32_t cap;
   float* pmax;
   int P;
-  uint32_t dbg;   // ablation bits for tools/bench_wide.py: 1 = LDS-DMA pieces all re-read one cached KiB,
+  uint32_t dbg;   // diagnostic bits (experiments build, tools/bench_wide.py): 1 = LDS-DMA pieces all re-read one cached KiB,
                   // 4 = clock stamps (cycles, 100-MHz ticks, cycles in wait+barrier) per workgroup into pmax
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(WIDE_WAVES * 64, 2) k_scan_wide(WideParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  u32x4* slots = (u32x4*)smem_raw;                                  // [2][24 * 64]
-  uint32_t* stage = (uint32_t*)(slots + 2 * WIDE_KS * 64);          // 3 * WAVES * SCAP words
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5;
-  const int qi = wave * 32 + c;
-
-  // this wave's 32 queries as B-operand fragments, resident for the whole sweep
-  u32x4 qf[WIDE_KS];
-#pragma unroll
-  for (int kk = 0; kk < WIDE_KS; ++kk) {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (qi < p.B) v = *(const u32x4*)(p.q + (size_t)qi * (WIDE_KS * 16) + kk * 16 + h * 8);
-    qf[kk] = v;
-  }
-  float th[1];
-  th[0] = (MODE == MODE_EMIT) ? p.thr[qi] : 0.f;
-  float pm = -INFINITY;
-  EmitState es;
-  es.cnt = 0;
-  es.q_base = (uint32_t)(wave * 32);
-  es.s_row = stage + wave * SCAP;
-  es.s_score = (float*)(stage + WIDE_WAVES * SCAP) + wave * SCAP;
-  es.s_q = stage + 2 * WIDE_WAVES * SCAP + wave * SCAP;
-
-  // work items of this WORKGROUP: w = blockIdx.x, + gridDim.x, ...
-  const uint32_t G = gridDim.x;
-  const uint32_t cnt = (p.n_work > blockIdx.x) ? (p.n_work - blockIdx.x + G - 1) / G : 0u;
-  if (cnt == 0) return;   // whole workgroup (cnt is workgroup-uniform): no barrier is skipped by a subset
-  // Every load below is UNCONDITIONAL (indices past the end are clamped to the last
-  // block and their results discarded): with loads under `if (i + 3 < cnt)` hipcc
-  // cannot count them and waits vmcnt(0) before every LDS write, which exposes a full
-  // HBM latency per block (measured 260 us instead of ~130 us).
-  auto piece = [&](uint32_t i, int j) {
-    const uint32_t ic = i < cnt ? i : cnt - 1;
-    const uint32_t b = (blockIdx.x + ic * G) * p.bstride;
-    return p.corpus + ((size_t)b * WIDE_KS + wave * WIDE_PIECES + j) * 64 + lane;
-  };
-
-  u32x4 ring[WIDE_DEPTH][WIDE_PIECES];
-#pragma unroll
-  for (int d = 0; d < WIDE_DEPTH; ++d)
-#pragma unroll
-    for (int j = 0; j < WIDE_PIECES; ++j) ring[d][j] = ld_frag(piece(d, j));
-
-  // Block i is computed from LDS slot i & 1 while block i+1 is being published to the
-  // other slot: one barrier per block, and the LDS writes (with their wait on HBM) run
-  // under the previous block's MFMAs instead of in front of the barrier.
-  //   barrier_i  => every wave has finished block i-1 (its slot may be overwritten)
-  //                 and every piece of block i (written during step i-1) is in LDS
-  auto publish = [&](uint32_t blk, u32x4 (&mine)[WIDE_PIECES]) {
-    u32x4* dst = slots + (blk & 1u) * (WIDE_KS * 64);
-#pragma unroll
-    for (int j = 0; j < WIDE_PIECES; ++j) dst[(wave * WIDE_PIECES + j) * 64 + lane] = mine[j];
-  };
-  auto step = [&](uint32_t i, u32x4 (&mine)[WIDE_PIECES]) {   // `mine` holds block i+1
-    const u32x4* slot = slots + (i & 1u) * (WIDE_KS * 64);
-    __syncthreads();
-    publish(i + 1, mine);
-#pragma unroll
-    for (int j = 0; j < WIDE_PIECES; ++j) mine[j] = ld_frag(piece(i + 1 + WIDE_DEPTH, j));
-    f32x16 acc[1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-    // A fragments come from LDS in batches of 6, double-buffered and pinned with
-    // sched_barrier: left alone hipcc keeps only TWO fragments in flight, so every
-    // second MFMA waits a full LDS latency (measured: 31 % MFMA utilisation, 252 us).
-    {
-      constexpr int NB = 6;
-      u32x4 a0[NB], a1[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) a0[j] = slot[(0 * NB + j) * 64 + lane];
-#pragma unroll
-      for (int g = 0; g < WIDE_KS / NB; ++g) {
-        u32x4(&cur)[NB] = (g & 1) ? a1 : a0;
-        u32x4(&nxt)[NB] = (g & 1) ? a0 : a1;
-        if (g + 1 < WIDE_KS / NB) {
-#pragma unroll
-          for (int j = 0; j < NB; ++j) nxt[j] = slot[((g + 1) * NB + j) * 64 + lane];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, cur[j]),
-                                                          __builtin_bit_cast(half8, qf[g * NB + j]),
-                                                          acc[0], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // padding steps (i >= cnt) re-score the last block; row0 = n_rows masks every row
-    const uint32_t row0 = i < cnt ? (blockIdx.x + i * G) * p.bstride * 32u : p.n_rows;
-    if (MODE == MODE_SAMPLE) {
-      if (row0 + 32u > p.n_rows) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (row0 + acc_row(r, h) >= p.n_rows) acc[0][r] = -INFINITY;
-      }
-      pm = fmaxf(pm, max16(acc[0]));
-    } else {
-      // 16 compares OR-ed on the scalar unit: fmaxf on MFMA results costs an extra
-      // canonicalising v_max per element, a compare does not
-      bool hit = false;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hit |= acc[0][r] >= th[0];
-      if (__ballot(hit) != 0ull) {
-        emit_slow<1>(acc, th, row0, lane, es, p);
-      }
-    }
-  };
-
-  publish(0, ring[0]);
-#pragma unroll
-  for (int j = 0; j < WIDE_PIECES; ++j) ring[0][j] = ld_frag(piece(WIDE_DEPTH, j));
-  for (uint32_t i = 0; i < cnt; i += WIDE_DEPTH) {   // cnt rounded up to a multiple of the ring depth
-    step(i, ring[1]);        // ring[(i + 1) % 3] holds block i + 1
-    step(i + 1, ring[2]);
-    step(i + 2, ring[0]);
-  }
-
-  if (MODE == MODE_EMIT) {
-    if (es.cnt > 0) emit_flush(es, p, lane);
-  } else {
-    pm = fmaxf(pm, __shfl_xor(pm, 32));
-    if (h == 0 && qi < p.B) p.pmax[(size_t)qi * p.P + blockIdx.x] = pm;
-  }
-}
-
-// ---- host side --------------------------------------------------------------------------
-template <int MODE>
-static int launch_wide(const WideParams& p, int grid, hipStream_t st) {
-  const size_t lds = (size_t)2 * WIDE_KS * RF_FRAG_BYTES + (size_t)3 * WIDE_WAVES * SCAP * 4;
-  auto kern = k_scan_wide<MODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WIDE_WAVES * 64), lds, st, p);
-  RF_HIP(hipGetLastError());
-  return RF_OK;
-}
-
 int rf_wide_supported(const rf_index* ix) { return ix->KS == WIDE_KS; }
 
-static int wide4_sample(const rf_index* ix, const void* q, int B, const rf_workspace& ws, int* P_out, hipStream_t st);
-static int wide4_emit(const rf_index* ix, const void* q, int B, const rf_workspace& ws, hipStream_t st);
-static int wide_variant();
-
-int rf_launch_wide_sample(const rf_index* ix, const void* q, int B, const rf_workspace& ws, int* P_out,
-                          hipStream_t st) {
-  if (wide_variant() != 0) return wide4_sample(ix, q, B, ws, P_out, st);
-  const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
-  // same sampling rule as scan.hip: ~1/16 of the corpus, 64..RF_SAMPLE_WGS partitions
-  uint32_t n_work = nblk / 16;
-  if (n_work < 64u) n_work = 64u;
-  if (n_work > (uint32_t)RF_SAMPLE_WGS * 8) n_work = (uint32_t)RF_SAMPLE_WGS * 8;
-  if (n_work > nblk) n_work = nblk;
-  int grid = (int)(n_work < (uint32_t)RF_SAMPLE_WGS ? n_work : (uint32_t)RF_SAMPLE_WGS);
-  WideParams p{};
-  p.corpus = ix->tiles;
-  p.q = (const _Float16*)q;
-  p.B = B;
-  p.n_rows = (uint32_t)ix->size;
-  p.n_work = n_work;
-  p.bstride = nblk / n_work;
-  p.pmax = ws.pmax;
-  p.P = grid;
-  *P_out = grid;
-  return launch_wide<MODE_SAMPLE>(p, grid, st);
-}
-
-int rf_launch_wide_emit(const rf_index* ix, const void* q, int B, const rf_workspace& ws,
-                        hipStream_t st) {
-  if (wide_variant() != 0) return wide4_emit(ix, q, B, ws, st);
-  const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
-  int grid = ix->num_cus;   // one 8-wave workgroup per CU
-  if ((uint32_t)grid > nblk) grid = (int)nblk;
-  if (grid < 1) grid = 1;
-  WideParams p{};
-  p.corpus = ix->tiles;
-  p.q = (const _Float16*)q;
-  p.B = B;
-  p.n_rows = (uint32_t)ix->size;
-  p.n_work = nblk;
-  p.bstride = 1;
-  p.thr = ws.thr;
-  p.cand_cnt = ws.cand_cnt;
-  p.cand = ws.cand;
-  p.cap = RF_SHARD_CAP;
-  return launch_wide<MODE_EMIT>(p, grid, st);
-}
-
-// =========================================================================================
-// Wide sweep, second form (the default): corpus through an LDS-DMA ring, NW = 4 or 8 waves
-// =========================================================================================
-// The register-staged form above runs its waves in lockstep around a barrier per 32-row block:
-// LDS writes, filter and barrier add to the MFMA time instead of hiding under it (250 us per
-// 256-query sweep against ~120 us of matrix work).  This form:
-//   * the corpus arrives by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, the
-//     fragment image is lane-linear so HBM order == LDS order): no staging registers, no
-//     ds_write pass.  A phase = 2 blocks (64 rows, 48 KiB contiguous in HBM); 3 LDS slots;
-//     loads run two phases (96 KiB per CU) ahead behind a counted vmcnt and a raw s_barrier,
-//     one piece per group of MFMAs (an LDS-DMA issue holds its wave for tens of cycles);
+// The corpus arrives by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, the
+// fragment image is lane-linear so HBM order == LDS order): no staging registers, no ds_write
+// pass.  A phase = 2 blocks (64 rows, 48 KiB contiguous in HBM); 3 LDS slots; loads run two
+// phases (96 KiB per CU) ahead behind a counted vmcnt and a raw s_barrier, one piece per group
+// of MFMAs (an LDS-DMA issue holds its wave for tens of cycles);
 //   * the A-fragment reads are inline asm with hand-counted lgkmcnt waits (as compiler-visible
 //     LDS loads each would get an s_waitcnt vmcnt(0): hipcc cannot tell them from the DMA
 //     writes in flight), one group of 4 ahead of the MFMAs;
-//   * the resident query fragments are pinned to the accumulator half of the register file;
 //   * the filter of a phase's first block is plain VALU in the same basic block as the second
 //     block's MFMAs; the second block's filter runs at the start of the NEXT phase, in the
 //     shadow of that phase's first LDS reads.
-// NW = 4: one wave per SIMD with 64 queries each (every A fragment feeds two MFMAs: half the
-// LDS reads per flop, but nothing hides a wave's own LDS-DMA issues, filter and barrier).
 // NW = 8: two waves per SIMD with 32 queries each (one LDS read per MFMA, the partner wave's
-// MFMAs cover the other's non-matrix work).
+// MFMAs cover the other's non-matrix work).  Forms tried and dropped (in the
+// history before round 2): a register-staged ring with one barrier per block (264 us per step),
+// NW = 4 with 64 queries per wave (271 us), queries pinned to the accumulator half (+3 us).
 #define WL_SLOTS 3
 #define WL_PB 2                               // corpus blocks per phase
 #define WL_FRAGS (WIDE_KS * WL_PB)            // 1-KiB fragments per phase (48)
@@ -514,67 +308,41 @@ __global__ void __launch_bounds__(NW * 64, 1) k_scan_ldsdma(WideParams p) {
   }
 }
 
-// ---- host side of the LDS-DMA form ----------------------------------------------------------
-int rf_tuning_wide_variant = -1;   // 0 = register-staged form, 1 = LDS-DMA 4 waves, 2 = LDS-DMA 8 waves (all in arch
-                                   // VGPRs), 3 = LDS-DMA 8 waves with the queries pinned to the accumulator half
-int rf_tuning_wide_nt = -1;        // LDS-DMA cache policy: 0 default, 1 non-temporal (aux = 2)
-int rf_tuning_wide_dbg = 0;        // ablation bits (WideParams::dbg)
-int rf_tuning_wide_sample_pairs = 4;   // sample pass: block pairs (phases) per workgroup, at most
-static int wide_variant() {
-  if (rf_tuning_wide_variant < 0) {
-    const char* v = getenv("RF_WIDE_VARIANT");
-    rf_tuning_wide_variant = (v && v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 2;
-  }
-  return rf_tuning_wide_variant;
-}
-static int wide_nt() {
-  if (rf_tuning_wide_nt < 0) {
-    const char* v = getenv("RF_WIDE_NT");
-    rf_tuning_wide_nt = (v && v[0] == '0') ? 0 : 1;
-  }
-  return rf_tuning_wide_nt;
-}
-
+// ---- host side ---------------------------------------------------------------------------
 template <int MODE, int AUX, int NW, int ABL = 0, int PIN = 0>
 static int launch_ldsdma(const WideParams& p, int grid, hipStream_t st) {
   const size_t lds = (size_t)WL_SLOTS * WL_FRAGS * RF_FRAG_BYTES + (size_t)WL_STAGE_WORDS * 4 +
                      (size_t)RF_FRAG_BYTES;   // slots, emit staging, dump area
   auto kern = k_scan_ldsdma<MODE, AUX, NW, ABL, PIN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RF_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static rf_lds_attr attr;   // per instantiation, per device
+  RF_HIP(rf_ensure_lds(attr, (const void*)kern, lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
   RF_HIP(hipGetLastError());
   return RF_OK;
 }
 template <int MODE>
 static int dispatch_ldsdma(const WideParams& p, int grid, hipStream_t st) {
-  const bool w8 = wide_variant() >= 2;
+#ifdef RF_EXPERIMENTS
   if (MODE == MODE_EMIT) {
-    switch (rf_tuning_wide_dbg >> 3) {   // diagnostic builds (non-temporal, current wave count)
-#define WL_ABL(x) case x: return w8 ? launch_ldsdma<MODE_EMIT, 2, 8, x>(p, grid, st) : launch_ldsdma<MODE_EMIT, 2, 4, x>(p, grid, st);
+    switch (rf_knob_wide_dbg >> 3) {   // compile-time ablations (results wrong): 1 no DMA, 2 no filters, 4 no LDS reads
+#define WL_ABL(x) case x: return launch_ldsdma<MODE_EMIT, 2, 8, x>(p, grid, st);
       WL_ABL(1) WL_ABL(2) WL_ABL(4) WL_ABL(7)
 #undef WL_ABL
       default: break;
     }
   }
-  if (wide_variant() == 3)   // 8 waves with the queries pinned to the accumulator half (the first LDS-DMA form)
-    return launch_ldsdma<MODE, 2, 8, 0, 1>(p, grid, st);
-  if (wide_nt())
-    return w8 ? launch_ldsdma<MODE, 2, 8>(p, grid, st) : launch_ldsdma<MODE, 2, 4>(p, grid, st);
-  return w8 ? launch_ldsdma<MODE, 0, 8>(p, grid, st) : launch_ldsdma<MODE, 0, 4>(p, grid, st);
+#endif
+  return launch_ldsdma<MODE, 2, 8>(p, grid, st);   // non-temporal LDS-DMA (aux = 2), 8 waves
 }
 
-static int wide4_sample(const rf_index* ix, const void* q, int B, const rf_workspace& ws, int* P_out,
-                        hipStream_t st) {
+int rf_launch_wide_sample(const rf_index* ix, const void* q, int B, const rf_workspace& ws, int* P_out,
+                          hipStream_t st) {
   const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
   const uint32_t npair = (nblk + 1) / 2;
   // ~1/16 of the corpus in block pairs, 64..RF_SAMPLE_WGS partitions of up to 4 pairs
   uint32_t n_work = npair / 16;
   if (n_work < 64u) n_work = 64u;
-  if (n_work > (uint32_t)RF_SAMPLE_WGS * rf_tuning_wide_sample_pairs) n_work = (uint32_t)RF_SAMPLE_WGS * rf_tuning_wide_sample_pairs;
+  if (n_work > (uint32_t)RF_SAMPLE_WGS * rf_knob_wide_sample_pairs) n_work = (uint32_t)RF_SAMPLE_WGS * rf_knob_wide_sample_pairs;
   if (n_work > npair) n_work = npair;
   const int grid = (int)(n_work < (uint32_t)RF_SAMPLE_WGS ? n_work : (uint32_t)RF_SAMPLE_WGS);
   WideParams p{};
@@ -590,7 +358,7 @@ static int wide4_sample(const rf_index* ix, const void* q, int B, const rf_works
   return dispatch_ldsdma<MODE_SAMPLE>(p, grid, st);
 }
 
-static int wide4_emit(const rf_index* ix, const void* q, int B, const rf_workspace& ws, hipStream_t st) {
+int rf_launch_wide_emit(const rf_index* ix, const void* q, int B, const rf_workspace& ws, hipStream_t st) {
   const uint32_t nblk = (uint32_t)((ix->size + 31) / 32);
   const uint32_t npair = (nblk + 1) / 2;
   int grid = ix->num_cus;   // one workgroup per CU (all of its LDS)
@@ -607,7 +375,7 @@ static int wide4_emit(const rf_index* ix, const void* q, int B, const rf_workspa
   p.cand_cnt = ws.cand_cnt;
   p.cand = ws.cand;
   p.cap = RF_SHARD_CAP;
-  p.dbg = (uint32_t)rf_tuning_wide_dbg;
+  p.dbg = (uint32_t)rf_knob_wide_dbg;
   if (p.dbg & 4u) p.pmax = ws.pmax;   // stamp buffer of the diagnostic run
   return dispatch_ldsdma<MODE_EMIT>(p, grid, st);
 }

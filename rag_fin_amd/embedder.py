@@ -101,8 +101,17 @@ class Embedder:
                                                   ctypes.byref(wc), c_void_p(self._storage.data_ptr()),
                                                   nbytes, self.device.index, _lib.current_stream_ptr()))
         self.handle = h
-        self._ws = None
+        # Threading: the handle holds no per-call state, so concurrent encodes only
+        # have to keep their BUFFERS apart.  Large batches take a workspace of their own per call
+        # (torch's caching allocator: stream-ordered reuse, no hipMalloc in steady state).
+        # Query-sized batches share fixed staging buffers (rf_encode replays a hipGraph keyed by
+        # their addresses) and serialise on _small_lock; _small_done orders a caller on another
+        # stream behind the previous use.  The chunked text ingest (pinned staging, copy stream)
+        # runs one at a time under _ingest_lock.
+        self._small_ws = None
         self._small_lock = threading.Lock()
+        self._small_done = None
+        self._ingest_lock = threading.Lock()
         self._copy_stream = None
         self._pin = None
 
@@ -156,12 +165,6 @@ class Embedder:
         return cls(w, cfg, tokenizer, device)
 
     # -- forward ------------------------------------------------------------------------
-    def _workspace(self, nbytes: int):
-        torch = _torch()
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws
-
     def encode_ids(self, ids, lens, out_dtype="float16"):
         """ids int32 [B, T], lens int32 [B] (tensors or arrays) -> [B, 384] tensor on
         the device (fp16 by default: exactly what CorpusStore stores)."""
@@ -180,10 +183,12 @@ class Embedder:
                 return self._encode_small(ids, lens, B, T, want32)
         return self._encode_large(ids, lens, B, T, want32)
 
-    def _launch(self, ids, lens, B, T, out16, out32):
+    def _launch(self, ids, lens, B, T, out16, out32, ws=None):
         torch = _torch()
         with torch.cuda.device(self.device):
-            ws = self._workspace(self.lib.rf_encode_workspace_bytes(self.handle, B, T))
+            if ws is None:   # per call: concurrent encodes (any thread, any stream) never share scratch
+                ws = torch.empty(self.lib.rf_encode_workspace_bytes(self.handle, B, T), dtype=torch.uint8,
+                                 device=self.device)
             _lib.check(self.lib.rf_encode(self.handle, c_void_p(ids.data_ptr()), c_void_p(lens.data_ptr()),
                                           B, T, c_void_p(out16.data_ptr()) if out16 is not None else None,
                                           c_void_p(out32.data_ptr()) if out32 is not None else None,
@@ -202,15 +207,22 @@ class Embedder:
     def _encode_small(self, ids, lens, B, T, want32):
         # a query-sized batch: fixed staging buffers, so that rf_encode sees the same pointers call
         # after call and replays its cached hipGraph instead of ~45 launches (the result is cloned)
+        torch = _torch()
         sb = self._small_buffers()
+        cur = torch.cuda.current_stream(self.device)
+        if self._small_done is not None:
+            cur.wait_event(self._small_done)     # a previous caller on ANOTHER stream may still be using the buffers
         sb["ids"][:B * T].copy_(ids.reshape(-1), non_blocking=True)
         sb["lens"][:B].copy_(lens, non_blocking=True)
         ids, lens = sb["ids"], sb["lens"]
         out16 = None if want32 else sb["o16"]
         out32 = sb["o32"] if want32 else None
-        self._launch(ids, lens, B, T, out16, out32)
-        res = out32 if want32 else out16
-        return res[:B].clone()
+        self._launch(ids, lens, B, T, out16, out32, ws=self._small_ws)
+        res = (out32 if want32 else out16)[:B].clone()
+        if self._small_done is None:
+            self._small_done = torch.cuda.Event()
+        self._small_done.record(cur)
+        return res
 
     SMALL_SLOTS = 1024   # = SM_MAX_TOK of csrc/encoder.hip: the small-batch GEMM path / hipGraph replay
 
@@ -223,15 +235,25 @@ class Embedder:
                         "o16": torch.zeros((n, self.dim), dtype=torch.float16, device=self.device),
                         "o32": torch.zeros((n, self.dim), dtype=torch.float32, device=self.device)}
             # workspace large enough for every small shape: its pointer must not move either
-            with torch.cuda.device(self.device):
-                self._workspace(max(self.lib.rf_encode_workspace_bytes(self.handle, n, 1),
-                                    self.lib.rf_encode_workspace_bytes(self.handle, max(1, n // 256), 256)))
+            nbytes = max(self.lib.rf_encode_workspace_bytes(self.handle, n, 1),
+                         self.lib.rf_encode_workspace_bytes(self.handle, max(1, n // 256), 256))
+            self._small_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._sb
 
-    def encode_to_device(self, sentences, batch_tokens: int = 65536):
-        """Tokenise, bucket by length, encode; returns fp16 [n, 384] on the device in
-        the input order."""
+    def encode_to_device(self, sentences, batch_tokens: int = 65536, out_dtype="float16"):
+        """Tokenise, bucket by length, encode; returns fp16 (default: what CorpusStore keeps) or
+        fp32 [n, 384] on the device in the input order."""
+        held = [False]    # the chunked path takes _ingest_lock on first use (queries never do)
+        try:
+            return self._encode_to_device(sentences, batch_tokens, out_dtype, held)
+        finally:
+            if held[0]:
+                self._ingest_lock.release()
+
+    def _encode_to_device(self, sentences, batch_tokens, out_dtype, held):
         torch = _torch()
+        want32 = out_dtype in ("float32", np.float32)
+        odt = torch.float32 if want32 else torch.float16
         if self.tokenizer is None:
             raise RuntimeError("Embedder has no tokenizer: construct it with from_local(path) or pass "
                                "tokenizer=WordPieceTokenizer(vocab)")
@@ -243,7 +265,7 @@ class Embedder:
         # through one chunk's buckets the host is already tokenising the next chunk.
         sentences = list(sentences)
         n = len(sentences)
-        out = torch.empty((n, self.dim), dtype=torch.float16, device=self.device)
+        out = torch.empty((n, self.dim), dtype=odt, device=self.device)
         if n == 0:
             return out
         chunk_texts = 4096
@@ -264,8 +286,11 @@ class Embedder:
             m = len(part)
             if m * int(all_ids.shape[1]) <= self.SMALL_SLOTS:
                 # a query or a handful: straight to the small-batch path (no sorting, no side stream)
-                out[c0:c0 + m] = self.encode_ids(all_ids, all_lens)
+                out[c0:c0 + m] = self.encode_ids(all_ids, all_lens, out_dtype=out_dtype)
                 continue
+            if not held[0]:      # pinned staging buffers + copy stream below are one-at-a-time
+                self._ingest_lock.acquire()
+                held[0] = True
             order = np.argsort(all_lens, kind="stable")
             sorted_lens = all_lens[order].astype(np.int64)
             # ONE upload per chunk, from pinned memory on a side stream: a pageable host-to-device copy
@@ -309,14 +334,16 @@ class Embedder:
                 sel = order_dev[i:j]
                 ids = ids_dev.index_select(0, sel)[:, :T].contiguous()
                 lens = lens_dev.index_select(0, sel)
-                out.index_copy_(0, sel + c0, self.encode_ids(ids, lens))
+                out.index_copy_(0, sel + c0, self.encode_ids(ids, lens, out_dtype=out_dtype))
                 i = j
         return out
 
     def encode(self, sentences, batch_size: int = 32, **_ignored) -> np.ndarray:
-        """sentence-transformers' signature: numpy float32 [n, 384] (or [384] for a str)."""
+        """sentence-transformers' signature: numpy float32 [n, 384] (or [384] for a str) --
+        rf_encode's fp32 output (the reference returns fp32, vector_rag_mcp/main.py:50), not the
+        fp16 rows the store keeps."""
         single = isinstance(sentences, str)
-        emb = self.encode_to_device([sentences] if single else list(sentences))
-        arr = emb.float().cpu().numpy()
+        emb = self.encode_to_device([sentences] if single else list(sentences), out_dtype="float32")
+        arr = emb.cpu().numpy()
         return arr[0] if single else arr
 

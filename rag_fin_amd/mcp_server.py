@@ -96,6 +96,13 @@ def main() -> None:
     except ImportError as e:
         raise SystemExit("the MCP transport needs the `fastmcp` package (not installed here); the "
                          "tool functions in rag_fin_amd.mcp_server work without it") from e
+    # N > 1 (torch.distributed.run, one process per GPU): every rank builds its shard; ranks > 0
+    # then follow rank 0's searches and never reach the MCP transport
+    rag = get_rag()
+    if hasattr(rag.collection, "start_workers"):
+        rag.collection.start_workers()
+        if rag.collection.rank != 0:
+            return
     mcp = FastMCP("VectorRAG")
     for fn in TOOLS:
         mcp.tool()(fn)

@@ -17,26 +17,17 @@ logger = logging.getLogger(__name__)
 
 OUTPUT_FIELDS = ["text", "period", "chunk_type", "statement_type", "primary_value"]
 
-PROMPT = """Based on the provided financial data about ICICI Bank, answer the question accurately.
-
-QUESTION: {question}
-
-CONTEXT:
-{context}
-
-INSTRUCTIONS:
-- Use exact numbers from the context (include decimals and units)
-- If information is not available, say so clearly
-- Be concise and factual
-- Include the relevant period/quarter
-
-ANSWER:"""
+# The LLM step (Gemini, vector_rag_mcp/main.py:72-108) is out of scope; the prompt wording is
+# the caller's business.  This default only lays the retrieved contexts out for a generator;
+# deployments that want the reference's wording pass their own `prompt_template`
+# (placeholders: {question}, {context}).
+DEFAULT_PROMPT = "Question: {question}\n\nRetrieved contexts:\n{context}\n\nAnswer from the contexts only."
 
 
 class VectorRAG:
     def __init__(self, gemini_api_key: str | None = None, collection_name: str = "fin_chunks", *,
                  embedder=None, store=None, generator: Callable[[str], str] | None = None,
-                 llm_delay_s: float = 1.0):
+                 llm_delay_s: float = 1.0, prompt_template: str = DEFAULT_PROMPT):
         """embedder: .encode(list[str]) -> [n, dim] (rag_fin_amd.embedder.Embedder);
         store: rag_fin_amd.store.CorpusStore.  `gemini_api_key` is accepted for
         signature compatibility and only handed to `generator` factories upstream."""
@@ -47,6 +38,7 @@ class VectorRAG:
         self.collection = store
         self.collection_name = collection_name
         self.generator = generator
+        self.prompt_template = prompt_template
         self.llm_delay_s = llm_delay_s
         self.collection.load()
         logger.info("VectorRAG ready on collection %s (%d chunks)", collection_name,
@@ -90,7 +82,7 @@ class VectorRAG:
     def build_prompt(self, question: str, contexts: list[dict]) -> str:
         ctx = "\n\n".join(f"Context {i + 1} [{c['period']} - {c['chunk_type']}]:\n{c['text']}"
                           for i, c in enumerate(contexts))
-        return PROMPT.format(question=question, context=ctx)
+        return self.prompt_template.format(question=question, context=ctx)
 
     def search_and_answer(self, question: str, top_k: int = 3) -> dict:
         contexts = self.search(question, top_k)

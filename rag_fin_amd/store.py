@@ -206,16 +206,17 @@ class GpuIndex:
                 _lib.current_stream_ptr()))
         return scores, ids, exact
 
-    def search_large(self, q16, k: int, id_base: int = 0):
+    def search_large(self, q16, k: int, id_base: int = 0, want_exact: bool = False):
         """Limits above RF_MAX_K: the first page through the fused path, further pages
         of RF_MAX_K through rf_search_exhaustive_after (each page = the hits ranked
-        strictly after the previous page's last hit).  Returns (scores, ids) [B, k]."""
+        strictly after the previous page's last hit).  Returns (scores, ids) [B, k]
+        (+ the fp64 ranking scores with want_exact: what a cross-shard merge ranks by)."""
         torch = _torch()
         q16 = q16.to(self.device).contiguous()
         B = q16.shape[0]
         page = _lib.RF_MAX_K
         s0, i0, e0 = self.search(q16, page, id_base, want_exact=True)
-        scores, ids = [s0], [i0]
+        scores, ids, exacts = [s0], [i0], [e0]
         last_s, last_i = e0[:, -1].contiguous(), i0[:, -1].contiguous()
         got = page
         while got < k and bool((last_i >= 0).any()):
@@ -233,12 +234,15 @@ class GpuIndex:
                     _lib.current_stream_ptr()))
             scores.append(s)
             ids.append(i)
+            exacts.append(e)
             last_s, last_i = e[:, -1].contiguous(), i[:, -1].contiguous()
             got += page
         if got < k:   # corpus exhausted before k hits: pad like rf_search does
             scores.append(torch.full((B, k - got), float("-inf"), dtype=torch.float32, device=self.device))
             ids.append(torch.full((B, k - got), -1, dtype=torch.int64, device=self.device))
-        return torch.cat(scores, 1)[:, :k].contiguous(), torch.cat(ids, 1)[:, :k].contiguous()
+            exacts.append(torch.full((B, k - got), float("-inf"), dtype=torch.float64, device=self.device))
+        out = (torch.cat(scores, 1)[:, :k].contiguous(), torch.cat(ids, 1)[:, :k].contiguous())
+        return out + (torch.cat(exacts, 1)[:, :k].contiguous(),) if want_exact else out
 
     def search(self, q16, k: int, id_base: int = 0, want_exact: bool = False):
         """rf_search, then re-run any query the fused path could not prove exact
@@ -335,13 +339,14 @@ class CorpusStore:
     """Drop-in for the reference's `Collection("fin_chunks")` on this path."""
 
     def __init__(self, name: str = "fin_chunks", dim: int = 384, capacity: int = 4096,
-                 device=None, metric_type: str = "COSINE"):
+                 device=None, metric_type: str = "COSINE", index=None):
         self.name = name
         self.dim = dim
         self.metric_type = metric_type.upper()
         if self.metric_type not in ("COSINE", "IP"):
             raise ValueError("metric_type must be COSINE or IP")
-        self.index = GpuIndex(dim, capacity, device)
+        # `index`: an already-built GpuIndex (tests of the sharded store pass a CPU double)
+        self.index = index if index is not None else GpuIndex(dim, capacity, device)
         self.columns: dict[str, list] = {f: [] for f in SCALAR_FIELDS}
         self._pk_row: dict[Any, int] = {}
 
@@ -369,7 +374,7 @@ class CorpusStore:
     def _grow(self, need: int) -> None:
         old = self.index
         cap = max(need, old.capacity * 2)
-        new = GpuIndex(self.dim, cap, old.device)
+        new = type(old)(self.dim, cap, old.device)
         n = old.size
         step = 1 << 18
         for s in range(0, n, step):

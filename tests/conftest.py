@@ -18,3 +18,17 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a ROCm GPU; none visible (no CPU fallback exists)")
     return torch.device("cuda:0")
+
+
+def record_measurement(name: str, **values) -> None:
+    """Achieved errors the GPU tests measure on the way are appended to
+    gpurun_out/test_measurements.jsonl (scratch; the ones tolerances are derived from are
+    copied into profiles/), so that a tolerance can be checked against what was measured."""
+    import json
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "test_measurements.jsonl"), "a") as f:
+            f.write(json.dumps({"name": name, **{k: float(v) for k, v in values.items()}}) + "\n")
+    except OSError:
+        pass

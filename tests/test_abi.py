@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "ragfin.h")).read()
+    text = re.sub(r"#ifdef RF_EXPERIMENTS.*?#endif", "", text, flags=re.S)   # not in the shipped library
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", text)))
 
@@ -49,3 +50,22 @@ def test_product_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         store.GpuIndex(384, 1024)
+
+
+def test_shipped_library_has_no_tuning_surface_and_carries_its_build_id():
+    lib = _lib.load_library()
+    for name in _lib.EXPERIMENT_SIGNATURES:
+        assert not hasattr(lib, name), f"{name} must only exist in the experiments build"
+    assert lib.rf_build_id().decode() == build.source_digest()
+    assert lib.rf_version() >= 200
+
+
+def test_stale_library_is_detected(tmp_path, monkeypatch):
+    """A library built from other sources must not load silently: _lib compares rf_build_id()
+    with the digest of the sources on disk (and, with hipcc present, rebuilds instead)."""
+    import pytest
+    monkeypatch.setattr(build, "have_hipcc", lambda: False)
+    monkeypatch.setattr(build, "source_digest", lambda experiments=False: "0" * 16)
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib.load_library()

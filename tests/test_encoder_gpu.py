@@ -1,9 +1,14 @@
 """GPU parity tests for the embedder half of the hot path (rf_encode through the C
 ABI) against the numpy oracle (oracle/encoder.py, itself pinned to transformers'
-BertModel by tests/golden).  Tolerance: the GPU computes in fp16 storage / fp32
-accumulate; the oracle evaluates the SAME fp16-rounded weights in float64.
-Bar: cosine >= 0.999 and max-abs <= 1e-2 on unit-norm outputs;
-asserted tighter here (5e-3) because that is what the kernels achieve."""
+BertModel by tests/golden).  The GPU computes in fp16 storage / fp32 accumulate; the
+oracle evaluates the SAME fp16-rounded weights in float64.
+
+Tolerances = 3x what tools/measure_encoder_error.py measured at the FULL architecture
+(6 layers, T up to 256, vocab 30 522; profiles/r02a_encoder_error.json): max-abs 1.5e-4
+(fp32 output) / 1.6e-4 (fp16 output), L2 9.3e-4, 1 - cos 4.1e-7, on unit-norm rows whose
+components are ~0.05.  north_star's bound on the SCORE (|cos| within 1e-3) follows from the L2
+bound: |<a,b> - <a',b'>| <= |a - a'| + |b - b'| <= 2 * 9.3e-4 worst case, measured 1.5e-4; it
+is asserted directly in tests/test_end_to_end_gpu.py and tests/test_config4_gpu.py."""
 import os
 
 import numpy as np
@@ -13,7 +18,11 @@ from oracle import encoder as oenc
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL = 5e-3
+TOL = 4.5e-4          # max-abs per component, fp32 output (3 x 1.5e-4 measured)
+TOL16 = 5e-4          # fp16 output (3 x 1.6e-4)
+TOL_L2 = 2.8e-3       # per-row L2 error (3 x 9.3e-4)
+TOL_COS = 1.3e-6      # 1 - cos (3 x 4.1e-7)
+GOLDEN_TOL = 1e-2     # vs fp32-weight transformers outputs: includes the fp16 rounding of the weights
 
 
 def run(cfg, seed, ids, lens, device):
@@ -26,13 +35,19 @@ def run(cfg, seed, ids, lens, device):
     return got, got32, want
 
 
-def check(got, got32, want):
+def check(got, got32, want, name=None):
+    from conftest import record_measurement
     assert np.isfinite(got).all()
-    assert np.abs(got32 - want).max() < TOL, np.abs(got32 - want).max()
-    assert np.abs(got - want).max() < TOL + 1e-3
+    e32, e16 = np.abs(got32 - want).max(), np.abs(got - want).max()
+    l2 = np.linalg.norm(got32 - want, axis=1).max()
     cos = (got32 * want).sum(1) / np.linalg.norm(got32, axis=1) / np.linalg.norm(want, axis=1)
-    assert cos.min() > 0.9995, cos.min()
-    assert np.abs(np.linalg.norm(got32, axis=1) - 1).max() < 1e-4
+    if name:
+        record_measurement(name, max_abs_f32=e32, max_abs_f16=e16, l2_max=l2, one_minus_cos=1 - cos.min())
+    assert e32 < TOL, e32
+    assert e16 < TOL16, e16
+    assert l2 < TOL_L2, l2
+    assert 1 - cos.min() < TOL_COS, 1 - cos.min()
+    assert np.abs(np.linalg.norm(got32, axis=1) - 1).max() < 1e-6   # fp32 rounding of a unit vector
 
 
 @pytest.mark.parametrize("name", ["tiny", "minilm_l6"])
@@ -40,9 +55,13 @@ def test_encoder_matches_golden_and_oracle(gpu_device, name):
     z = np.load(os.path.join(GOLD, f"encoder_{name}.npz"))
     cfg = {k: (float(v) if k == "ln_eps" else int(v)) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
     got, got32, want = run(cfg, int(z["seed"]), z["ids"], z["lens"], gpu_device)
-    check(got, got32, want)
-    # and against the transformers-generated golden (fp32 weights, so a looser bound)
-    assert np.abs(got32 - z["emb"]).max() < 1e-2
+    check(got, got32, want, f"encoder_golden_{name}")
+    # and against the transformers-generated golden itself: fp32 WEIGHTS there, fp16-rounded ones
+    # here, so this bound is mostly the weight rounding's (recorded; see GOLDEN_TOL)
+    from conftest import record_measurement
+    eg = np.abs(got32 - z["emb"]).max()
+    record_measurement(f"encoder_vs_transformers_golden_{name}", max_abs=eg)
+    assert eg < GOLDEN_TOL, eg
 
 
 @pytest.mark.parametrize("B,T,lo", [(1, 7, 7), (3, 256, 1), (70, 33, 1), (16, 128, 100)])
@@ -53,7 +72,7 @@ def test_encoder_ragged_batches(gpu_device, B, T, lo):
     lens[0] = T
     ids = rng.integers(1, 2000, (B, T)).astype(np.int32)
     got, got32, want = run(cfg, 5, ids, lens, gpu_device)
-    check(got, got32, want)
+    check(got, got32, want, f"encoder_ragged_{B}x{T}")
 
 
 def test_padding_content_and_width_are_ignored(gpu_device):
@@ -105,59 +124,61 @@ def test_text_encode_end_to_end_with_synthetic_vocab(gpu_device):
     assert got.shape == (37, 384) and got.dtype == np.float32
     ids, lens = tok.batch(texts, 64)
     want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids, lens)
-    assert np.abs(got - want).max() < TOL + 1e-3
+    assert np.abs(got - want).max() < TOL                 # encode() returns rf_encode's fp32 output
     one = emb.encode(texts[5])
-    assert one.shape == (384,) and np.abs(one - got[5]).max() < 2e-3
+    assert one.shape == (384,) and np.abs(one - got[5]).max() < TOL   # small-batch path vs bucketed path
 
 
 def test_all_gemm_paths_agree_and_match_the_oracle(gpu_device):
-    """The encoder has three GEMM paths chosen by batch size -- feature-split + separate
-    LayerNorm (<= 1024 token slots), direct-load tiles, and weights through the LDS-DMA ring
-    (>= 8192 slots, QKV / FFN1).  A 10 240-slot batch is run through the two large-batch
-    paths, a 512-slot batch through small and direct; outputs must agree with each other
-    to fp16 resolution and with the numpy oracle (2 layers, checked on a row subset)."""
-    from rag_fin_amd import _lib
+    """The encoder has four GEMM paths chosen by the batch's token slots: feature-split +
+    separate LayerNorm (<= 1024), direct-load tiles (< 8192), weights through the LDS-DMA ring
+    with 128-token workgroups (>= 8192, QKV / FFN1) and with 256-token workgroups (>= 49 152).
+    A sequence's embedding does not depend on what else is in the batch, so the SAME 8 sequences
+    are encoded inside batches of each size class: the results must agree with each other to
+    fp16 resolution and with the numpy oracle (2 layers)."""
     from rag_fin_amd.embedder import Embedder
-    lib = _lib.load_library()
     cfg = dict(oenc.MINILM_L6, layers=2, vocab_size=3000)
     w = oenc.random_weights(cfg, 11)
     emb = Embedder(w, cfg, device=gpu_device)
     rng = np.random.default_rng(3)
+    T = 64
+    lens8 = rng.integers(1, T + 1, 8).astype(np.int32)
+    lens8[0] = T
+    ids8 = rng.integers(1, 3000, (8, T)).astype(np.int32)
+    want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids8, lens8)
 
-    def enc(ids, lens, **knobs):
-        try:
-            for k, v in knobs.items():
-                _lib.check(lib.rf_set_tuning(k.encode(), v))
-            return emb.encode_ids(ids, lens, out_dtype="float32").cpu().numpy()
-        finally:
-            for k in knobs:
-                lib.rf_set_tuning(k.encode(), 0 if k == "ln_tail" else 1)   # back to the defaults
+    def in_batch(B):   # the 8 probe sequences first, random filler after
+        lens = np.concatenate([lens8, rng.integers(1, T + 1, B - 8).astype(np.int32)])
+        ids = np.concatenate([ids8, rng.integers(1, 3000, (B - 8, T)).astype(np.int32)])
+        return emb.encode_ids(ids, lens, out_dtype="float32").cpu().numpy()[:8]
 
-    B, T = 40, 256                                   # 10 240 slots: LDS-DMA ring by default
-    lens = rng.integers(30, T + 1, B).astype(np.int32)
-    lens[0] = T
-    ids = rng.integers(1, 3000, (B, T)).astype(np.int32)
-    dma = enc(ids, lens)
-    direct = enc(ids, lens, linear_dma=0)
-    dma_wide = enc(ids, lens, linear_dma=2)          # 256-token workgroups (default from 49 152 slots)
-    assert np.abs(dma - direct).max() < 2e-3
-    assert np.array_equal(dma, dma_wide)             # same arithmetic per (token, feature): bit-identical
-    sub = [0, 1, 7, 39]
-    want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids[sub], lens[sub])
-    assert np.abs(dma[sub] - want).max() < TOL and np.abs(direct[sub] - want).max() < TOL
+    small = in_batch(16)          # 1 024 slots
+    direct = in_batch(64)         # 4 096
+    dma = in_batch(160)           # 10 240
+    dma_wide = in_batch(800)      # 51 200
+    for name, got in (("small", small), ("direct", direct), ("dma", dma), ("dma_wide", dma_wide)):
+        assert np.abs(got - want).max() < TOL, (name, np.abs(got - want).max())
+    assert np.abs(small - direct).max() < 2 * TOL and np.abs(dma - direct).max() < 2 * TOL
+    assert np.array_equal(dma, dma_wide)     # same arithmetic per (token, feature): bit-identical
+    one = emb.encode_ids(ids8[:1, :16], np.array([12], dtype=np.int32), out_dtype="float32").cpu().numpy()
+    want1 = oenc.encode(oenc.round_weights_fp16(w), cfg, ids8[:1, :16], np.array([12], dtype=np.int32))
+    assert np.abs(one - want1).max() < TOL   # a single 12-token query (the reference's serving mode)
 
-    B, T = 8, 64                                     # 512 slots: small-batch path by default
-    lens = rng.integers(1, T + 1, B).astype(np.int32)
-    ids = rng.integers(1, 3000, (B, T)).astype(np.int32)
-    small = enc(ids, lens)
-    direct = enc(ids, lens, linear_small=0)
-    # LayerNorm by the GEMM's last-arriving workgroup (knob ln_tail=1; measured slower, off by default)
-    # vs as its own launch: same arithmetic on the same fp32 sums -> bit-identical, call after call
-    # (the hand-off counters re-arm themselves)
-    for _ in range(3):
-        assert np.array_equal(enc(ids, lens, ln_tail=1), small)
-    one = enc(ids[:1, :16], np.array([12], dtype=np.int32))          # a single 12-token query
-    assert np.array_equal(enc(ids[:1, :16], np.array([12], dtype=np.int32), ln_tail=1), one)
-    want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids, lens)
-    assert np.abs(small - direct).max() < 2e-3
-    assert np.abs(small - want).max() < TOL and np.abs(direct - want).max() < TOL
+
+def test_large_batch_forward_repeats_bitwise(gpu_device):
+    """Short soak of the LDS-DMA GEMMs (k_linear_dma waits on hand-counted vmcnt / lgkmcnt values;
+    a misplaced count gives a RARE wrong tile): 40 forwards of a 66 k-slot batch on fresh ids,
+    each compared bitwise with a second run of the same input."""
+    import torch
+    from rag_fin_amd.embedder import Embedder
+    cfg = dict(oenc.MINILM_L6, layers=2, vocab_size=3000)
+    emb = Embedder(oenc.random_weights(cfg, 13), cfg, device=gpu_device)
+    gen = torch.Generator(device=gpu_device).manual_seed(3)
+    B, T = 260, 256
+    for rnd in range(40):
+        ids = torch.randint(1, 3000, (B, T), device=gpu_device, generator=gen, dtype=torch.int32)
+        lens = torch.randint(8, T + 1, (B,), device=gpu_device, generator=gen, dtype=torch.int32)
+        a = emb.encode_ids(ids, lens).clone()
+        b = emb.encode_ids(ids, lens)
+        assert torch.equal(a, b), rnd
+        assert bool(torch.isfinite(a.float()).all())

@@ -10,6 +10,7 @@ import os
 import numpy as np
 import pytest
 
+from conftest import record_measurement
 from oracle import c_oracle, encoder as oenc, search as osearch
 
 pytestmark = pytest.mark.gpu
@@ -50,7 +51,9 @@ def test_ingest_matches_oracle_embeddings(rig):
     assert lens.max() <= 256 and lens.min() > 20
     want = oenc.encode(oenc.round_weights_fp16(rig["w"]), rig["cfg"], ids, lens)
     got = rig["store"].index.get_rows(np.arange(16)).float().cpu().numpy()
-    assert np.abs(got - want).max() < 6e-3
+    err = np.abs(got - want).max()
+    record_measurement("config1_ingest_rows_vs_oracle", max_abs=err, l2_max=np.linalg.norm(got - want, axis=1).max())
+    assert err < 5e-4          # fp16 rows: 3 x the 1.6e-4 measured at T = 256 (profiles/r02a_encoder_error.json)
     assert rig["store"].num_entities == 16
 
 
@@ -66,11 +69,42 @@ def test_search_top5_equals_oracle_on_stored_vectors(rig):
         assert [c["text"] for c in ctx] == [rig["chunks"][i]["text"] for i in oi[0]]
         assert np.allclose([c["score"] for c in ctx], os_[0], atol=1e-6)
         assert all(-1.001 <= c["score"] <= 1.001 for c in ctx)
-        # against the all-CPU pipeline (oracle encoder + oracle search): scores within 1e-2
+
+
+NORTH_STAR_TOL = 1e-3     # BASELINE.json north_star: "scores within 1e-3 fp16"
+MEASURED_TOL = 4.5e-4     # 3 x the 1.5e-4 measured over all pairs (profiles/r02a_encoder_error.json)
+
+
+def test_north_star_gpu_pipeline_vs_all_cpu_pipeline(rig):
+    """GPU encode -> GPU search against oracle encode -> oracle search on the reference's own
+    corpus (vector_rag_mcp/main.py:50-70 end to end): every returned score within 1e-3 of the
+    CPU pipeline's score for the same chunk (asserted at 3x the measured error), and the GPU
+    ranking is a valid ranking of the CPU scores up to that error (two chunks may swap only if
+    their CPU scores are closer than twice the error)."""
+    rag = rig["rag"]
+    texts = [c["text"] for c in rig["chunks"]]
+    wq = oenc.round_weights_fp16(rig["w"])
+    ids, lens = rig["tok"].batch(texts, 256)
+    c_or = oenc.encode(wq, rig["cfg"], ids, lens).astype(np.float32).astype(np.float16)
+    row_of = {t: i for i, t in enumerate(texts)}
+    worst = 0.0
+    for qtext in QUESTIONS:
         ids, lens = rig["tok"].batch([qtext], 256)
-        qo = oenc.encode(oenc.round_weights_fp16(rig["w"]), rig["cfg"], ids, lens)
-        full = (qo @ c16.astype(np.float64).T)[0]
-        assert np.abs(full[oi[0]] - os_[0]).max() < 1e-2
+        q_or = oenc.encode(wq, rig["cfg"], ids, lens).astype(np.float32).astype(np.float16)
+        full_or = osearch.exact_scores(q_or, c_or)[0]
+        os_, oi = c_oracle.search(q_or, c_or, 5)
+        ctx = rag.search(qtext, 5)
+        rows = [row_of[c["text"]] for c in ctx]
+        got = np.array([c["score"] for c in ctx])
+        diff = np.abs(got - full_or[rows]).max()
+        worst = max(worst, diff)
+        assert diff <= MEASURED_TOL <= NORTH_STAR_TOL, diff
+        assert np.all(full_or[rows][:-1] >= full_or[rows][1:] - 2 * MEASURED_TOL)      # order valid up to the error
+        assert np.all(full_or[rows] >= os_[0][-1] - 2 * MEASURED_TOL)                  # nothing outside the CPU top-5 band
+        top6 = np.sort(full_or)[::-1][:6]
+        if np.min(top6[:-1] - top6[1:]) > 2 * MEASURED_TOL:                           # well separated: identical ranking
+            assert rows == list(oi[0])
+    record_measurement("config1_north_star_score_diff", max_abs=worst)
 
 
 def test_top_k_larger_than_corpus_returns_all_rows_once(rig):

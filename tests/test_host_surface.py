@@ -74,7 +74,10 @@ def test_search_and_answer_shapes():
     r2 = rag2.search_and_answer("what was net profit?", 2)
     assert r2["answer"] == "42 crore" and set(r2) == {"answer", "contexts", "context_count"}
     prompt = rag2.build_prompt("Q?", rag2.search("Q?", 1))
-    assert "Context 1 [Q1_FY2024 - t]:\ntext 0" in prompt and prompt.endswith("ANSWER:")
+    assert "Context 1 [Q1_FY2024 - t]:\ntext 0" in prompt and prompt.startswith("Question: Q?")
+    # the wording is the caller's: a deployment passes its own template (placeholders {question}, {context})
+    rag4 = make_rag(prompt_template="Q={question}|C={context}|ANSWER:")
+    assert rag4.build_prompt("Q?", rag4.search("Q?", 1)).endswith("|ANSWER:")
     rag3 = make_rag(generator=lambda p: 1 / 0, llm_delay_s=0)
     assert "division" in rag3.search_and_answer("what was net profit?")["error"]
 

@@ -16,6 +16,8 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+MODEL_DIR_TOL = 1e-2          # tightened to 3x measured once recorded (see record_measurement below)
+MODEL_DIR_COS_TOL = 1e-3
 TEXTS = ["What was the total income in Q1 2024?", "Net profit rose 12.5% year over year.",
          "capital adequacy ratio", "Gross NPA • provisions ₹1,234.50 crore",
          "retail banking segment results for the quarter ended June 30, 2023"]
@@ -99,8 +101,14 @@ def test_from_local_text_to_embedding_matches_transformers(tmp_path, gpu_device)
     for i in range(len(texts)):
         assert ids[i, :lens[i]].tolist() == enc["input_ids"][i][:int(enc["attention_mask"][i].sum())].tolist()
     cos = (got * want).sum(1)
-    assert cos.min() > 0.999, cos.min()
-    assert np.abs(got - want).max() < 1e-2, np.abs(got - want).max()    # fp16 weights / activations
-    # and the single-string form of SentenceTransformer.encode
+    err = np.abs(got - want).max()
+    from conftest import record_measurement
+    record_measurement("model_dir_vs_transformers_fp32", max_abs=err, one_minus_cos=1 - cos.min(),
+                       l2_max=np.linalg.norm(got - want, axis=1).max())
+    # transformers runs fp32 WEIGHTS; the GPU stores them as fp16, so this bound is the weight
+    # rounding's plus the kernels' (kernels alone: 1.5e-4, profiles/r02a_encoder_error.json)
+    assert 1 - cos.min() < MODEL_DIR_COS_TOL, 1 - cos.min()
+    assert err < MODEL_DIR_TOL, err
+    # and the single-string form of SentenceTransformer.encode (small-batch GEMM path)
     one = emb.encode(texts[0])
-    assert one.shape == (384,) and np.abs(one - got[0]).max() < 2e-3
+    assert one.shape == (384,) and np.abs(one - got[0]).max() < 4.5e-4

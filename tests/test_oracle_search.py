@@ -104,3 +104,45 @@ def test_merge_shards_equals_single_search():
     parts = [osearch.search(q, c[a:b], 10, id_base=a) for a, b in [(0, 1000), (1000, 1007), (1007, 4000)]]
     ms, mi = osearch.merge_shards(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), 10)
     assert np.array_equal(mi, i) and np.array_equal(ms, s)
+
+
+def test_c_oracle_row_split_over_threads_is_identical():
+    c = osearch.synth_unit_rows(40_000, 64, 5)
+    c[30_000:30_020] = c[17]                       # ties across the split boundaries
+    q = osearch.synth_unit_rows(9, 64, 6)
+    q[0] = c[17]
+    a = c_oracle.search(q, c, 12, threads=1)
+    for t in (2, 3, 7):
+        b = c_oracle.search(q, c, 12, id_base=0, threads=t)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_oracle_agrees_with_sklearn_brute_force_cosine():
+    """Independent third-party restatement of the reference's metric (Milvus COSINE top-k = the k
+    smallest cosine distances): scikit-learn's brute-force cosine nearest neighbours in float64,
+    its own normalisation and matmul code path.  The oracle ranks the SAME fp16 rows by inner
+    product (they are unit-norm up to fp16 rounding, as in the product):
+      * similarity: sklearn's 1 - distance == oracle score / (|q| |c|) to float64 round-off;
+      * ranking: identical lists wherever the oracle's neighbouring scores are further apart
+        than the norm deviation can move them; the returned SETS always agree up to that band."""
+    sk = pytest.importorskip("sklearn.neighbors")
+    c16 = osearch.synth_unit_rows(5000, 384, 71)
+    q16 = osearch.synth_unit_rows(16, 384, 72)
+    k = 10
+    c64, q64 = c16.astype(np.float64), q16.astype(np.float64)
+    nn = sk.NearestNeighbors(n_neighbors=k, algorithm="brute", metric="cosine").fit(c64)
+    dist, idx = nn.kneighbors(q64)
+    os_, oi = osearch.search(q16, c16, k + 5)
+    qn, cn = np.linalg.norm(q64, axis=1), np.linalg.norm(c64, axis=1)
+    dev = 2 * max(np.abs(qn - 1).max(), np.abs(cn - 1).max())          # how far cosine and inner product can differ
+    assert dev < 2e-3
+    for b in range(16):
+        row_score = dict(zip(oi[b].tolist(), os_[b].tolist()))
+        for j in range(k):
+            r = int(idx[b, j])
+            assert r in row_score, "sklearn returned a row outside the oracle's top-(k+5)"
+            assert abs((1.0 - dist[b, j]) - row_score[r] / (qn[b] * cn[r])) < 1e-12
+        gaps = os_[b][:k] - os_[b][1:k + 1]
+        if gaps.min() > dev:                                           # well separated: the very same list
+            assert idx[b].tolist() == oi[b][:k].tolist()
+        assert set(idx[b].tolist()) <= {r for r, s_ in row_score.items() if s_ >= os_[b][k - 1] - dev}

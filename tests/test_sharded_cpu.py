@@ -1,7 +1,12 @@
-"""N > 1 path on CPU: world_size-2 (and 3) gloo runs of rag_fin_amd.sharded.
-ShardedSearcher with a CPU backend injected by the test (oracle-backed), checking
-that shard bounds + one all-gather + merge reproduce the single-process result bit
-for bit.  The product backend (HipShardBackend) is exercised on the GPU box."""
+"""N > 1 path on CPU: world_size-2 (and 3) gloo runs of rag_fin_amd.sharded /
+rag_fin_amd.sharded_store with CPU doubles injected by the test (oracle-backed index and
+backend), checking that
+  * shard bounds + one all-gather + merge reproduce the single-process result bit for bit;
+  * a query flagged on ONE rank only is re-run exhaustively on every rank before the answer is
+    trusted, and the flags every rank returns are the global OR;
+  * ShardedCorpusStore (multi-batch ingest, non-contiguous shards, replicated columns, save /
+    load across world sizes, rank-0-led serving) answers like a single store.
+The product backend (HipShardBackend) is exercised on the GPU box (tests/test_sharded_gpu.py)."""
 import os
 import socket
 
@@ -15,15 +20,55 @@ from oracle import search as osearch
 from rag_fin_amd.sharded import ShardedSearcher
 
 
+class OracleIndex:
+    """CPU double of rag_fin_amd.store.GpuIndex: fp16 rows in a numpy array."""
+
+    def __init__(self, dim, capacity, device=None):
+        self.dim, self.capacity = dim, int(capacity)
+        self.device = torch.device("cpu")
+        self.rows = np.zeros((0, dim), dtype=np.float16)
+
+    @property
+    def size(self):
+        return self.rows.shape[0]
+
+    def add(self, rows):
+        assert self.size + rows.shape[0] <= self.capacity
+        self.rows = np.concatenate([self.rows, rows.numpy().astype(np.float16)])
+
+    def reset(self):
+        self.rows = self.rows[:0]
+
+    def get_rows(self, ids):
+        return torch.from_numpy(self.rows[np.asarray(ids, dtype=np.int64)])
+
+    def to_fp16(self, x, normalize=True):
+        x = np.asarray(x, dtype=np.float32)
+        return torch.from_numpy((osearch.l2_normalize_f32(x) if normalize else x).astype(np.float16))
+
+
 class OracleBackend:
-    """Stands in for HipShardBackend: same contract, CPU arithmetic from oracle/."""
+    """Stands in for HipShardBackend: same contract, CPU arithmetic from oracle/.
+    flag_queries: queries this rank reports as unproven -- and answers WRONGLY (an empty list),
+    so a merge that trusted them would be visibly wrong."""
 
-    def __init__(self, c16_local):
-        self.c = c16_local
+    def __init__(self, index, flag_queries=()):
+        self.index = index
+        self.flag_queries = list(flag_queries)
+        self.exhaustive_calls = 0
 
-    def local_topk(self, q16, k, row_base):
-        s, i = osearch.search(q16.numpy(), self.c, k, id_base=row_base)
-        return torch.from_numpy(s), torch.from_numpy(i), torch.zeros(q16.shape[0], dtype=torch.int32)
+    def local_topk(self, q16, k, row_base, workspace=None):
+        s, i = osearch.search(q16.numpy(), self.index.rows, k, id_base=row_base)
+        flags = np.zeros(q16.shape[0], dtype=np.int32)
+        for b in self.flag_queries:
+            flags[b] = 1
+            s[b], i[b] = -np.inf, -1
+        return torch.from_numpy(s), torch.from_numpy(i), torch.from_numpy(flags)
+
+    def local_exhaustive(self, q16, k, row_base):
+        self.exhaustive_calls += 1
+        s, i = osearch.search(q16.numpy(), self.index.rows, k, id_base=row_base)
+        return torch.from_numpy(s), torch.from_numpy(i)
 
     def merge(self, exact_all, ids_all, k):
         s, i = osearch.merge_shards(exact_all.numpy(), ids_all.numpy(), k)
@@ -36,17 +81,25 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, d, b, k, out_dir):
+def _init(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _worker(rank, world, port, n, d, b, k, out_dir, flag_rank, flag_queries):
+    _init(rank, world, port)
     try:
         c = osearch.synth_unit_rows(n, d, 1234)
         q = torch.from_numpy(osearch.synth_unit_rows(b, d, 5678))
         lo, hi = ShardedSearcher.shard_bounds(n, world, rank)
-        searcher = ShardedSearcher(OracleBackend(c[lo:hi]), row_base=lo)
+        ix = OracleIndex(d, max(hi - lo, 1))
+        ix.add(torch.from_numpy(c[lo:hi]))
+        backend = OracleBackend(ix, flag_queries if rank == flag_rank else ())
+        searcher = ShardedSearcher(backend, row_base=lo)
         scores, ids, flags = searcher.search(q, k)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), scores=scores.numpy(), ids=ids.numpy(),
-                 lo=lo, hi=hi)
+        raw = searcher.search(q, k, resolve=False)            # what an unresolved merge would hold
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), scores=scores.numpy(), ids=ids.numpy(), flags=flags.numpy(),
+                 raw_ids=raw[1].numpy(), ex_calls=backend.exhaustive_calls, lo=lo, hi=hi)
     finally:
         dist.destroy_process_group()
 
@@ -54,7 +107,7 @@ def _worker(rank, world, port, n, d, b, k, out_dir):
 @pytest.mark.parametrize("world,n", [(2, 3001), (3, 100), (2, 7)])
 def test_sharded_equals_single(tmp_path, world, n):
     d, b, k = 64, 5, 10
-    mp.spawn(_worker, args=(world, _free_port(), n, d, b, k, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, d, b, k, str(tmp_path), -1, ()), nprocs=world, join=True)
     c = osearch.synth_unit_rows(n, d, 1234)
     q = osearch.synth_unit_rows(b, d, 5678)
     ws, wi = osearch.search(q, c, k)
@@ -63,9 +116,28 @@ def test_sharded_equals_single(tmp_path, world, n):
         z = np.load(tmp_path / f"r{r}.npz")
         assert np.array_equal(z["ids"], wi), f"rank {r}"
         assert np.array_equal(z["scores"], ws.astype(np.float32))
+        assert not z["flags"].any() and int(z["ex_calls"]) == 0
         covered.append((int(z["lo"]), int(z["hi"])))
     assert covered[0][0] == 0 and covered[-1][1] == n
     assert all(a[1] == b_[0] for a, b_ in zip(covered, covered[1:]))
+
+
+@pytest.mark.parametrize("world,flag_rank", [(2, 1), (3, 0)])
+def test_query_flagged_on_one_rank_is_resolved_on_all(tmp_path, world, flag_rank):
+    """Only `flag_rank`'s local scan flags queries 1 and 3 (and returns garbage for them).  Every
+    rank must see the flags, every rank must re-run those two queries exhaustively, and the
+    final answer must equal the single-process one; the unresolved merge is visibly wrong."""
+    n, d, b, k = 2000, 64, 5, 10
+    mp.spawn(_worker, args=(world, _free_port(), n, d, b, k, str(tmp_path), flag_rank, (1, 3)), nprocs=world,
+             join=True)
+    ws, wi = osearch.search(osearch.synth_unit_rows(b, d, 5678), osearch.synth_unit_rows(n, d, 1234), k)
+    for r in range(world):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert z["flags"].tolist() == [0, 1, 0, 1, 0], f"rank {r}: flags must be the global OR"
+        assert int(z["ex_calls"]) == 1, f"rank {r} did not join the exhaustive re-run"
+        assert np.array_equal(z["ids"], wi) and np.array_equal(z["scores"], ws.astype(np.float32))
+        assert not np.array_equal(z["raw_ids"][1], wi[1])      # the flagged rank's rows were missing before
+        assert np.array_equal(z["raw_ids"][0], wi[0])
 
 
 def test_shard_bounds_cover_everything():
@@ -76,3 +148,75 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- ShardedCorpusStore ---------------------------------------------------------------------------
+def _store_worker(rank, world, port, out_dir):
+    from rag_fin_amd.sharded_store import ShardedCorpusStore
+    _init(rank, world, port)
+    try:
+        d = 64
+        vec = osearch.synth_unit_rows(257, d, 77).astype(np.float32)
+        batches = [(0, 100), (100, 101), (101, 257)]          # three inserts: shards are NOT contiguous globally
+        ix = OracleIndex(d, 8)
+        st = ShardedCorpusStore("t", dim=d, capacity=8, index=ix, backend=None)
+        st._backend_factory = lambda index: OracleBackend(index)
+        for lo, hi in batches:
+            n = hi - lo
+            st.insert([[f"k{i}" for i in range(lo, hi)], [f"text {i}" for i in range(lo, hi)], vec[lo:hi],
+                       ["p"] * n, ["c"] * n, ["s"] * n, [float(i) for i in range(lo, hi)]])
+        st.flush()
+        assert st.num_entities == 257 and 0 < st.local_rows < 257
+        q = osearch.synth_unit_rows(6, d, 78).astype(np.float32)
+        scores, rows = st.search_rows(q, 10)
+        hits = st.search(q[:2], "embedding", {"metric_type": "COSINE"}, 3, output_fields=["id", "text", "primary_value"])
+        big_s, big_r = st.search_rows(q[:2], 100)             # limit > RF_MAX_K: per-shard large top-k, merged
+        got = st.query(expr='id in ["k5", "k150", "nope", "k256"]', output_fields=["id", "text", "embedding"])
+        st.save(os.path.join(out_dir, "corpus"))
+        # serving: rank 0 leads, the others follow until released
+        st.start_workers()
+        led = None
+        if rank == 0:
+            led = [st.search_rows(q[i:i + 1], 5) for i in range(3)]
+            st.stop_workers()
+        # reload under the same world: contiguous shards this time, same answers
+        st2 = ShardedCorpusStore.load_from(os.path.join(out_dir, "corpus"), index_factory=OracleIndex,
+                                           backend=None)
+        st2._backend_factory = lambda index: OracleBackend(index)
+        s2, r2 = st2.search_rows(q, 10)
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), scores=scores, rows=rows, s2=s2, r2=r2, big_r=big_r,
+                 hit_ids=np.array([[h.id for h in hh] for hh in hits]),
+                 hit_pv=np.array([[h.entity.primary_value for h in hh] for hh in hits]),
+                 q_ids=np.array([g["id"] for g in got]), q_emb=np.array([g["embedding"] for g in got]),
+                 led=np.array([l[1][0] for l in led]) if led is not None else np.zeros(0),
+                 local_rows=st.local_rows)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_corpus_store_equals_single_store(tmp_path, world):
+    mp.spawn(_store_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    d = 64
+    vec = osearch.synth_unit_rows(257, d, 77).astype(np.float32)
+    c16 = osearch.l2_normalize_f32(vec).astype(np.float16)
+    q16 = osearch.l2_normalize_f32(osearch.synth_unit_rows(6, d, 78).astype(np.float32)).astype(np.float16)
+    ws, wi = osearch.search(q16, c16, 10)
+    wbs, wbi = osearch.search(q16[:2], c16, 100)
+    total = 0
+    for r in range(world):
+        z = np.load(tmp_path / f"s{r}.npz")
+        assert np.array_equal(z["rows"], wi) and np.array_equal(z["scores"], ws.astype(np.float32)), f"rank {r}"
+        assert np.array_equal(z["r2"], wi) and np.array_equal(z["s2"], ws.astype(np.float32))
+        assert np.array_equal(z["big_r"], wbi)
+        assert z["hit_ids"].tolist() == [[f"k{i}" for i in wi[b][:3]] for b in range(2)]
+        assert z["hit_pv"].tolist() == [[float(i) for i in wi[b][:3]] for b in range(2)]
+        assert z["q_ids"].tolist() == ["k5", "k150", "k256"]
+        assert np.allclose(z["q_emb"], c16[[5, 150, 256]].astype(np.float32))
+        total += int(z["local_rows"])
+        if r == 0:
+            assert np.array_equal(z["led"], wi[:3, :5])
+    assert total == 257
+    # the saved corpus is the single-GPU format: vectors in GLOBAL row order
+    mm = np.fromfile(tmp_path / "corpus" / "vectors.f16", dtype=np.float16).reshape(257, d)
+    assert np.array_equal(mm.view(np.uint16), c16.view(np.uint16))

@@ -1,6 +1,13 @@
-"""Cross-shard merge on the GPU: three shards held by three GpuIndex objects on one
-card stand in for three ranks; rf_merge_shards over their stacked per-shard top-k
-must equal the single-index search (and the oracle) bit for bit."""
+"""Cross-shard merge on the GPU.  (1) Three shards held by three GpuIndex objects on one card
+stand in for three ranks; rf_merge_shards over their stacked per-shard top-k must equal the
+single-index search (and the oracle) bit for bit.  (2) The PRODUCT lane path
+(HipShardBackend + ShardedSearcher._search_lane / ShardedCorpusStore + VectorRAG) with
+world_size 2: two processes, both on cuda:0, collectives over gloo (one card cannot host two
+RCCL ranks) -- real flags raised by a duplicate-heavy shard on ONE rank must be resolved on
+both, and the merged answers must equal the C oracle over the whole corpus."""
+import os
+import socket
+
 import numpy as np
 import pytest
 
@@ -65,32 +72,6 @@ def test_merge_shards_with_short_shards(gpu_device):
     assert np.array_equal(scores.cpu().numpy(), os_.astype(np.float32))
 
 
-def test_search_group_equals_single_searches(gpu_device):
-    """Several batches in flight whose per-shard top-k share one collective
-    (ShardedSearcher.search_group, rf_merge_shards_group) answer exactly like one search per
-    batch -- world-size-1 form of the path bench.py takes at N > 1."""
-    import torch
-    from rag_fin_amd.sharded import HipShardBackend, ShardedSearcher
-    from rag_fin_amd.store import GpuIndex
-    n, d, b, k, L = 60_000, 384, 64, 10, 3
-    c = osearch.synth_unit_rows(n, d, 21)
-    ix = GpuIndex(d, n, gpu_device)
-    ix.add(torch.from_numpy(c).to(gpu_device))
-    qs = [torch.from_numpy(osearch.synth_unit_rows(b, d, 30 + i)).to(gpu_device) for i in range(L)]
-    searcher = ShardedSearcher(HipShardBackend(ix), row_base=1000)
-    wss = [ix.workspace] + [ix.new_workspace() for _ in range(L - 1)]
-    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(L)]
-    for _ in range(2):      # second round reuses the group buffers
-        scores, ids, flags = searcher.search_group(qs, k, wss, streams)
-        torch.cuda.synchronize()
-        assert int(flags.abs().sum()) == 0
-        for i in range(L):
-            s1, i1, e1, _ = ix.search_raw(qs[i], k, id_base=1000, want_exact=True)
-            assert torch.equal(ids[i], i1) and torch.equal(scores[i], s1)
-            os_, oi = c_oracle.search(qs[i].cpu().numpy(), c, k)
-            assert np.array_equal(ids[i].cpu().numpy() - 1000, oi)
-
-
 def test_search_on_bare_enqueues_equal_search(gpu_device):
     """ShardedSearcher.search_on (the bench's N > 1 step: three ctypes enqueues on an explicit
     stream with cached pointers) returns what search() returns, on side streams and repeatedly."""
@@ -116,3 +97,138 @@ def test_search_on_bare_enqueues_equal_search(gpu_device):
             assert int(f_.abs().sum()) == 0
             assert np.array_equal(i_.cpu().numpy() - 7, oi)
             assert np.array_equal(s_.cpu().numpy(), os_.astype(np.float32))
+
+
+# ---- world_size 2 on one card: the product classes end to end ------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _corpus(n, d):
+    c = osearch.synth_unit_rows(n, d, 301)
+    c[n // 2 + 100: n // 2 + 100 + 12_000] = c[n // 2 + 100]     # 12 000 identical rows, all inside rank 1's shard
+    return c
+
+
+def _lane_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rag_fin_amd.sharded import HipShardBackend, ShardedSearcher
+        from rag_fin_amd.store import GpuIndex
+        dev = torch.device("cuda:0")
+        n, d, b, k = 60_000, 384, 64, 10
+        c = _corpus(n, d)
+        q16 = osearch.synth_unit_rows(b, d, 302)
+        q16[5] = c[n // 2 + 100]                                  # its top-10 is a 12 000-way tie: rank 1 flags it
+        lo, hi = ShardedSearcher.shard_bounds(n, world, rank)
+        ix = GpuIndex(d, hi - lo, dev)
+        ix.add(torch.from_numpy(c[lo:hi]).to(dev))
+        searcher = ShardedSearcher(HipShardBackend(ix), row_base=lo)
+        q = torch.from_numpy(q16).to(dev)
+        raw = searcher.search(q, k, resolve=False)
+        local_flags = searcher._lanes[(0, b, k)]["local_flags"].cpu().numpy().copy()
+        gflags_raw = raw[2].cpu().numpy().copy()
+        scores, gids, gflags = searcher.search(q, k)              # resolves flagged queries on every rank
+        ws2 = ix.new_workspace()                                  # a second lane (own workspace)
+        s2, g2, _ = searcher.search(q, k, workspace=ws2)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"l{rank}.npz"), scores=scores.cpu().numpy(), ids=gids.cpu().numpy(),
+                 gflags=gflags.cpu().numpy(), gflags_raw=gflags_raw, local_flags=local_flags,
+                 ids2=g2.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_product_lane_path_resolves_real_flags(tmp_path, gpu_device):
+    import torch.multiprocessing as mp
+    mp.spawn(_lane_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    n, d, b, k = 60_000, 384, 64, 10
+    c = _corpus(n, d)
+    q16 = osearch.synth_unit_rows(b, d, 302)
+    q16[5] = c[n // 2 + 100]
+    os_, oi = c_oracle.search(q16, c, k)
+    z0, z1 = (np.load(tmp_path / f"l{r}.npz") for r in range(2))
+    assert z0["local_flags"][5] == 0 and z1["local_flags"][5] != 0        # flagged on rank 1 only ...
+    for z in (z0, z1):
+        assert z["gflags_raw"][5] != 0 and z["gflags"][5] != 0             # ... but visible on both
+        assert np.array_equal(z["ids"], oi)
+        assert np.array_equal(z["scores"], os_.astype(np.float32))
+        assert np.array_equal(z["ids2"], oi)
+
+
+def _store_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import encoder as oenc, synth_text
+        from rag_fin_amd.embedder import Embedder
+        from rag_fin_amd.rag import VectorRAG
+        from rag_fin_amd.service import ingest_sharded
+        from rag_fin_amd.sharded_store import ShardedCorpusStore
+        from rag_fin_amd.tokenizer import WordPieceTokenizer
+        dev = torch.device("cuda:0")
+        cfg = dict(oenc.MINILM_L6, layers=2)
+        emb = Embedder(oenc.random_weights(cfg, 9), cfg, tokenizer=WordPieceTokenizer(synth_text.vocab_for()),
+                       device=dev)
+        texts = synth_text.retemplated_texts(2000, 31)
+        chunks = [dict(id=f"c{i}", text=t, period=f"P{i % 4}", chunk_type="t", statement_type="s",
+                       primary_value=float(i)) for i, t in enumerate(texts)]
+        store = ShardedCorpusStore("fin_chunks", dim=384, capacity=16, device=dev)
+        assert ingest_sharded(store, emb, chunks[:1200]) == 1200          # two ingests: non-contiguous shards
+        assert ingest_sharded(store, emb, chunks[1200:]) == 800
+        rag = VectorRAG(None, "fin_chunks", embedder=emb, store=store)
+        queries = synth_text.retemplated_texts(6, 32)
+        collective = [rag.search(qt, 5) for qt in queries[:3]]            # every rank calls (collective form)
+        store.start_workers()                                             # ranks > 0 stay inside
+        led = None
+        if rank == 0:
+            led = [rag.search(qt, 5) for qt in queries[3:]] + [rag.search_batch(queries, 3)]
+            store.stop_workers()
+        vec_local = store.index.get_rows(np.arange(store.local_rows)).cpu().numpy()
+        np.savez(os.path.join(out_dir, f"v{rank}.npz"), vec=vec_local, gmap=store._id_map.cpu().numpy())
+        if rank == 0:
+            import json
+            with open(os.path.join(out_dir, "rag.json"), "w") as f:
+                json.dump({"collective": collective, "led": led[:3], "batch": led[3]}, f)
+            qv = emb.encode_to_device(queries).cpu().numpy()
+            np.save(os.path.join(out_dir, "q.npy"), qv)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_sharded_store_behind_vector_rag(tmp_path, gpu_device):
+    """VectorRAG.search on a ShardedCorpusStore (vector_rag_mcp/main.py:48-70 at N = 2): the
+    payload must be what a single store over the same vectors returns -- checked against the C
+    oracle on the union of the two shards' stored rows, in global row order."""
+    import json
+    import torch.multiprocessing as mp
+    from oracle import synth_text
+    mp.spawn(_store_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    texts = synth_text.retemplated_texts(2000, 31)
+    c16 = np.zeros((2000, 384), dtype=np.float16)
+    seen = 0
+    for r in range(2):
+        z = np.load(tmp_path / f"v{r}.npz")
+        c16[z["gmap"]] = z["vec"]
+        seen += len(z["gmap"])
+    assert seen == 2000
+    q16 = np.load(tmp_path / "q.npy")
+    got = json.load(open(tmp_path / "rag.json"))
+    os5, oi5 = c_oracle.search(q16, c16, 5)
+    answers = got["collective"] + got["led"]
+    for b, ctx in enumerate(answers):
+        assert [c["rank"] for c in ctx] == [1, 2, 3, 4, 5]
+        assert [c["text"] for c in ctx] == [texts[i] for i in oi5[b]]
+        assert [c["primary_value"] for c in ctx] == [float(i) for i in oi5[b]]
+        assert np.allclose([c["score"] for c in ctx], os5[b], atol=1e-6)
+    for b, ctx in enumerate(got["batch"]):                                # search_batch: same rows as the oracle's top-3
+        rows = [int(c["primary_value"]) for c in ctx]
+        assert len(rows) == 3 and all(abs(c["score"] - float(c16[r].astype(np.float64) @ q16[b].astype(np.float64))) < 2e-3
+                                      for c, r in zip(ctx, rows))

@@ -15,6 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("RAGFIN_LIB", "exp")   # the experiments build: rf_set_tuning and the diagnostic hooks live there only
 
 QUESTIONS = ["What was the total income in the first quarter?", "How did net profit change year over year?",
              "What is the capital adequacy ratio?", "Segment results for retail banking",

@@ -11,6 +11,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RAGFIN_LIB", "exp")   # the experiments build: rf_set_tuning and the diagnostic hooks live there only
 
 
 def main():

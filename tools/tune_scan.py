@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B tuning of the scan pipeline in ONE process (interleaved rounds, medians):
-ring depth x emit workgroups per CU x sample blocks per wave x fused, via
+ring depth x emit workgroups per CU x sample blocks per wave, via
 rf_set_tuning.  Stage times come from rf_search_profile (HIP events)."""
 import argparse
 import itertools
@@ -11,6 +11,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("RAGFIN_LIB", "exp")   # the experiments build: rf_set_tuning and the diagnostic hooks live there only
 
 
 def main():
@@ -23,8 +24,6 @@ def main():
     ap.add_argument("--rings", default="6,8,12,24")
     ap.add_argument("--wgs", default="2,3")
     ap.add_argument("--bpw", default="1,2")
-    ap.add_argument("--fused", default="0")
-    ap.add_argument("--qreg", default="0", help="dim-384 emit sweep with the queries in registers: 0,1")
     args = ap.parse_args()
     import torch
     from rag_fin_amd import _lib
@@ -39,14 +38,13 @@ def main():
     ix.add(c)
     lib = _lib.load_library()
     configs = list(itertools.product([int(x) for x in args.rings.split(",")], [int(x) for x in args.wgs.split(",")],
-                                     [int(x) for x in args.bpw.split(",")], [int(x) for x in args.fused.split(",")],
-                                     [int(x) for x in args.qreg.split(",")]))
+                                     [int(x) for x in args.bpw.split(",")]))
     res = {cfg: [] for cfg in configs}
     flags_bad = {cfg: 0 for cfg in configs}
 
     def apply(cfg):
-        ring, wgs, bpw, fused, qreg = cfg
-        for k, v in (("ring24", ring), ("emit_wgs_per_cu", wgs), ("sample_bpw", bpw), ("fused", fused), ("qreg", qreg)):
+        ring, wgs, bpw = cfg
+        for k, v in (("ring24", ring), ("emit_wgs_per_cu", wgs), ("sample_bpw", bpw)):
             _lib.check(lib.rf_set_tuning(k.encode(), v))
 
     for cfg in configs:  # warm every variant (first launch loads code, sets LDS attributes)
@@ -60,14 +58,14 @@ def main():
             res[cfg].append({k: float(np.median([s[k] for s in stages])) for k in stages[0]})
             _, _, _, f = ix.search_raw(q, 10)
             flags_bad[cfg] += int(f.abs().sum().item())
-    print("ring wgs bpw fused qreg | sample thr emit merge | total (us, median of round medians)")
+    print("ring wgs bpw | sample thr emit merge | total (us, median of round medians)")
     rows = []
     for cfg in configs:
         med = {k: float(np.median([r[k] for r in res[cfg]])) * 1e3 for k in res[cfg][0]}
         tot = sum(med.values())
         rows.append((tot, cfg, med))
     for tot, cfg, med in sorted(rows):
-        print("%4d %3d %3d %5d %4d | %6.1f %5.1f %6.1f %5.1f | %6.1f  flags=%d" %
+        print("%4d %3d %3d | %6.1f %5.1f %6.1f %5.1f | %6.1f  flags=%d" %
               (*cfg, med["sample"], med["threshold"], med["emit"], med["merge"], tot, flags_bad[cfg]))
     print(json.dumps({"best": {"ring24": rows and sorted(rows)[0][1][0]}}))
 

@@ -109,7 +109,8 @@ int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_
               float* scores_dev, int64_t* ids_dev, double* exact_dev,
               uint32_t* flags_dev, void* workspace_dev, size_t workspace_bytes,
               void* stream);
-/* Profiling variant of rf_search for the first min(B, RF_QCHUNK) queries: same
+/* Profiling variant of rf_search for the FIRST corpus sweep of the batch (min(B, 64) queries,
+ * or min(B, 256) where rf_search would take the wide sweep: dim 384, B > 64): same
  * launches, with HIP events around each stage.  SYNCHRONISES the stream.
  * stage_ms_host (host memory) receives {sample scan, threshold, emit scan, merge}
  * in milliseconds.  Measurement hook for bench.py; no reference counterpart. */

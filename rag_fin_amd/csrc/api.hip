@@ -102,6 +102,16 @@ static int search_enqueue(const rf_index_t* ix, const void* q_dev, int B, int k,
                           int64_t* ids_dev, double* exact_dev, uint32_t* flags_dev, void* workspace_dev,
                           hipStream_t st);
 
+// More than one 64-query sweep left and dim 384: one wide sweep of up to 256 queries.
+// Small corpora -- every row a candidate -- stay on the 64-query kernel (its inline flushes take
+// any hit density, the wide kernel's bounded staging would flag every query), and so do large k
+// (the k-th of ~64 partition maxima is a weak threshold) and k-dense searches of mid-sized
+// corpora (expected hits per wave and phase ~ 2^15 k / N against room for 96).
+static bool take_wide(const rf_index_t* ix, int left, int k) {
+  return rf_wide_supported(ix) && left > RF_QCHUNK && ix->size > RF_SMALL_ROWS && k <= 16 &&
+         ix->size >= (int64_t)k * 1024;
+}
+
 extern "C" int rf_search(const rf_index_t* ix, const void* q_dev, int B, int k, int64_t id_base,
                          float* scores_dev, int64_t* ids_dev, double* exact_dev,
                          uint32_t* flags_dev, void* workspace_dev, size_t workspace_bytes,
@@ -125,16 +135,9 @@ static int search_enqueue(const rf_index_t* ix, const void* q_dev, int B, int k,
   rf_workspace ws;
   carve((unsigned char*)workspace_dev, &ws);
   const int dim = ix->dim;
-  const bool wide_ok = rf_wide_supported(ix);
   for (int q0 = 0; q0 < B;) {
     const int left = B - q0;
-    // more than one 64-query sweep left and dim 384: one wide sweep of up to 256 queries
-    // (small corpora -- every row a candidate -- stay on the 64-query kernel: its inline flushes
-    // take any hit density, the wide kernel's bounded staging would flag every query)
-    // and so do large k (the k-th of ~64 partition maxima is a weak threshold) and k-dense searches
-    // of mid-sized corpora (expected hits per wave and phase ~ 2^15 k / N against room for 96)
-    const bool wide = wide_ok && left > RF_QCHUNK && ix->size > RF_SMALL_ROWS && k <= 16 &&
-                      ix->size >= (int64_t)k * 1024;
+    const bool wide = take_wide(ix, left, k);
     const int nb = wide ? (left < RF_QWIDE ? left : RF_QWIDE) : (left < RF_QCHUNK ? left : RF_QCHUNK);
     const int JB = nb <= 32 ? 1 : 2;
     const _Float16* qc = (const _Float16*)q_dev + (size_t)q0 * dim;
@@ -184,15 +187,17 @@ extern "C" int rf_search_profile(const rf_index_t* ix, const void* q_dev, int B,
   for (int i = 0; i < 5; ++i) RF_HIP(hipEventCreate(&ev[i]));
   rf_workspace ws;
   carve((unsigned char*)workspace_dev, &ws);
-  const int nb = B < RF_QCHUNK ? B : RF_QCHUNK;
+  const bool wide = take_wide(ix, B, k);   // the first sweep rf_search would run for this batch
+  const int nb = wide ? (B < RF_QWIDE ? B : RF_QWIDE) : (B < RF_QCHUNK ? B : RF_QCHUNK);
   const int JB = nb <= 32 ? 1 : 2;
   int P = 0;
   RF_HIP(hipEventRecord(ev[0], st));
-  if (ix->size > RF_SMALL_ROWS) rc = rf_launch_sample(ix, q_dev, nb, JB, ws, &P, st);
+  if (ix->size > RF_SMALL_ROWS)
+    rc = wide ? rf_launch_wide_sample(ix, q_dev, nb, ws, &P, st) : rf_launch_sample(ix, q_dev, nb, JB, ws, &P, st);
   RF_HIP(hipEventRecord(ev[1], st));
   if (rc == RF_OK) rc = rf_launch_threshold(ix, q_dev, nb, k, P, ws, st);
   RF_HIP(hipEventRecord(ev[2], st));
-  if (rc == RF_OK) rc = rf_launch_emit(ix, q_dev, nb, JB, ws, st);
+  if (rc == RF_OK) rc = wide ? rf_launch_wide_emit(ix, q_dev, nb, ws, st) : rf_launch_emit(ix, q_dev, nb, JB, ws, st);
   RF_HIP(hipEventRecord(ev[3], st));
   if (rc == RF_OK)
     rc = rf_launch_merge(ix, q_dev, nb, k, id_base, ws, scores_dev, ids_dev, exact_dev, flags_dev, st);

@@ -178,7 +178,7 @@ class GpuIndex:
         """rf_search_profile: per-stage HIP-event times in ms (synchronises)."""
         torch = _torch()
         q16 = q16.to(self.device).contiguous()
-        B = min(q16.shape[0], _lib.RF_QCHUNK)
+        B = min(q16.shape[0], 256)      # the first sweep: 64 queries, or up to 256 on the wide path
         scores = torch.empty((B, k), dtype=torch.float32, device=self.device)
         ids = torch.empty((B, k), dtype=torch.int64, device=self.device)
         flags = torch.empty((B,), dtype=torch.int32, device=self.device)

@@ -22,7 +22,8 @@ TOL = 4.5e-4          # max-abs per component, fp32 output (3 x 1.5e-4 measured)
 TOL16 = 5e-4          # fp16 output (3 x 1.6e-4)
 TOL_L2 = 2.8e-3       # per-row L2 error (3 x 9.3e-4)
 TOL_COS = 1.3e-6      # 1 - cos (3 x 4.1e-7)
-GOLDEN_TOL = 1e-2     # vs fp32-weight transformers outputs: includes the fp16 rounding of the weights
+GOLDEN_TOL = 9e-4     # vs fp32-weight transformers outputs (includes the fp16 rounding of the weights):
+                      # 3 x the 3.0e-4 measured on the 6-layer golden (profiles/r02b_test_measurements.jsonl)
 
 
 def run(cfg, seed, ids, lens, device):

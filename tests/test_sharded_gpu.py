@@ -197,8 +197,10 @@ def _store_worker(rank, world, port, out_dir):
             import json
             with open(os.path.join(out_dir, "rag.json"), "w") as f:
                 json.dump({"collective": collective, "led": led[:3], "batch": led[3]}, f)
-            qv = emb.encode_to_device(queries).cpu().numpy()
-            np.save(os.path.join(out_dir, "q.npy"), qv)
+            # rag.search embeds ONE query per call, search_batch all six at once (another GEMM tile shape:
+            # the fp16 embedding may differ in the last bit), so the oracle gets each form's own vectors
+            np.save(os.path.join(out_dir, "q.npy"), np.concatenate([emb.encode_to_device([qt]).cpu().numpy() for qt in queries]))
+            np.save(os.path.join(out_dir, "qb.npy"), emb.encode_to_device(queries).cpu().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -228,7 +230,7 @@ def test_world2_sharded_store_behind_vector_rag(tmp_path, gpu_device):
         assert [c["text"] for c in ctx] == [texts[i] for i in oi5[b]]
         assert [c["primary_value"] for c in ctx] == [float(i) for i in oi5[b]]
         assert np.allclose([c["score"] for c in ctx], os5[b], atol=1e-6)
-    for b, ctx in enumerate(got["batch"]):                                # search_batch: same rows as the oracle's top-3
-        rows = [int(c["primary_value"]) for c in ctx]
-        assert len(rows) == 3 and all(abs(c["score"] - float(c16[r].astype(np.float64) @ q16[b].astype(np.float64))) < 2e-3
-                                      for c, r in zip(ctx, rows))
+    os3, oi3 = c_oracle.search(np.load(tmp_path / "qb.npy"), c16, 3)      # search_batch on rank 0 while leading
+    for b, ctx in enumerate(got["batch"]):
+        assert [int(c["primary_value"]) for c in ctx] == list(oi3[b])
+        assert np.allclose([c["score"] for c in ctx], os3[b], atol=1e-6)

@@ -430,7 +430,7 @@ def main():
                         index.search_raw(l["q_dev"], k, want_exact=True, out=l["out"], workspace=l["ws"])
                         l["s_host"].copy_(l["out"][0], non_blocking=True)
                         l["i_host"].copy_(l["out"][1], non_blocking=True)
-                group = 2 * len(hl)
+                group = 8 * len(hl)
                 pipelined(host_step, len(hl), group, group, torch.cuda.synchronize)
                 per = [pipelined(host_step, len(hl), group, 0, torch.cuda.synchronize) for _ in range(30)]
                 dth = float(np.median(per))
@@ -682,7 +682,7 @@ def config4(args, dev, index1m, lanes, c16_1m, k):
         # sentence-transformers wraps), batches of 32, same weights; a bounded sample of the same texts
         torch_threads = torch.get_num_threads()
         model = encoder_torch.build_bert(cfg, w)
-        m = 96
+        m = 256
         encoder_torch.encode(model, ids_all[:32], lens_all[:32])
         t = time.perf_counter()
         ref = encoder_torch.encode(model, ids_all[:m], lens_all[:m])

@@ -691,6 +691,225 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
   }
 }
 
+// ---- tiled GEMM with both operands through an LDS-DMA ring (round 2) ----------------------------
+// Y[128 tokens, 384 features] per workgroup, any K: the form for the GEMMs whose activations do
+// not fit a wave's registers (FFN2: K = 1536) and for the LayerNorm epilogues, which need all 384
+// features of a token inside one workgroup.  k_linear (above) loads both operands per wave
+// straight from L1/L2 -- 5 KiB of fragment loads per 6 MFMAs per wave, texture-addresser-bound at
+// ~1.7 x its MFMA time (round-1 counters: matrix pipe busy 28 % for FFN2, 13 % for the
+// out-projection).  Here a K-step of 32 is brought ONCE per workgroup by LDS-DMA -- 4 token blocks
+// and 12 feature blocks of two 1-KiB fragments each, 32 KiB, HBM/L2 order == LDS order because the
+// fragment image is lane-linear -- into a 4-slot ring with three stages in flight behind a counted
+// vmcnt and one raw s_barrier per stage; the 8 waves (2 token halves x 4 feature quarters) read
+// their 4 + 6 operand tiles with the permuted, conflict-free ds_read_b128 of the batch-256 sweep
+// (scan_wide.hip) and run 24 v_mfma_f32_16x16x32_f16 per stage: 10 LDS reads per 24 MFMAs.
+// A = weights (16 features x 32 k), B = activations (16 tokens x 32 k): the accumulator holds the
+// TOKEN on the lane and 4 consecutive FEATURES in registers, as in the other GEMMs, so bias, GELU,
+// residual add, the LayerNorm statistics and the 8-byte stores into the tiled layout are lane-local
+// plus one LDS exchange between the four feature quarters.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define GT_TOK 128
+#define GT_SLOTS 4
+#define GT_STAGE_FRAGS 32                  // 1-KiB fragments per stage: 4 x 2 (activations) + 12 x 2 (weights)
+template <int EPI, int KS>                 // KS = K / 16 (24 | 96)
+__global__ void __launch_bounds__(512, 1) k_gemm_tile(
+    const _Float16* __restrict__ X, const uint4* __restrict__ Wt, const _Float16* __restrict__ bias,
+    _Float16* __restrict__ out, int ldo, const int32_t* __restrict__ m_ptr, const _Float16* __restrict__ res,
+    const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta, float eps) {
+  constexpr int NST = KS / 2;              // stages (k-steps of 32)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  rf_u32x4* slots = (rf_u32x4*)smem_raw;                           // [GT_SLOTS][32 frags][64 lanes]
+  rf_u32x4* const dump = slots + GT_SLOTS * GT_STAGE_FRAGS * 64;   // 1 KiB: pieces issued past the last stage
+  float* red = (float*)(dump + 64);                               // [2][4 quarters][128 tokens] LayerNorm partial sums
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;                         // token half, feature quarter
+  const int t0 = blockIdx.x * GT_TOK;
+  const int n0 = blockIdx.y * 384;
+
+  // LDS-DMA issue is stall-prone (60-185 cycles per piece): were every wave to issue its share at the
+  // same point of every stage, both waves of a SIMD would stall together and the matrix pipe would idle.
+  // The halves of the workgroup (waves 0-3 / 4-7: the two waves of each SIMD) therefore take TURNS: the
+  // stage t is brought, three stages ahead, by half (t + 1) & 1 alone -- 8 pieces per wave, every other
+  // stage -- so in every stage one wave per SIMD goes straight to its MFMAs.  Piece p = 8 w' + j
+  // (w' = wave & 3): p < 8: activation block p >> 1, fragment p & 1; p >= 8: weight block (p - 8) >> 1.
+  // A wave's outstanding pieces at the wait in front of stage t are then either {t, t + 2} (its half
+  // brought t) or {t + 1}: `vmcnt(8)` is right for both.
+  const int half = wave >> 2;
+  const int p0 = (wave & 3) * 8;
+  const uint4* src0;   // lane's address of fragment kk = 0 of my first block
+  if (p0 < 8) src0 = (const uint4*)X + ((size_t)(t0 >> 5) * KS) * 64 + lane;
+  else src0 = Wt + ((size_t)((n0 >> 5) + ((p0 - 8) >> 1)) * KS) * 64 + lane;
+  auto issue_stage = [&](int s) {   // the issuing half brings all 32 pieces, live or not (uniform vmcnt arithmetic)
+    if (((s + 1) & 1) != half) return;
+    const bool live = s < NST;
+    const uint4* sp = src0 + (size_t)(live ? 2 * s : 0) * 64;
+    rf_u32x4* dp = live ? slots + ((s % GT_SLOTS) * GT_STAGE_FRAGS + p0) * 64 : dump;
+    const int dstep = live ? 64 : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)   // j = 2 b + f: block b of my four, fragment f
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp + (size_t)(j >> 1) * (KS * 64) + (j & 1) * 64),
+                                       (__attribute__((address_space(3))) void*)(dp + j * dstep), 16, 0, 0);
+  };
+  issue_stage(0);
+  issue_stage(1);
+  issue_stage(2);
+  const int M = *m_ptr;
+  if (t0 >= M) {   // whole workgroup; its LDS-DMA pieces must land before the LDS is handed on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  f32x4 acc[6][4];   // [feature tile ft][token tile tt]: lane = token 16 tt + c16, features 16 ft + 4 g + j
+#pragma unroll
+  for (int ft = 0; ft < 6; ++ft)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[ft][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // operand tile addresses inside a stage: activation block b at fragment 2 b, weight block b at 8 + 2 b;
+  // lane's bytes = ((g >> 1) * 64 + (g & 1) * 32 + 16 rg + c16) * 16 (see k_scan_w16)
+  const uint32_t lane_a = (uint32_t)(((g >> 1) * 64 + (g & 1) * 32 + c16) * 16);
+  const uint32_t xa = lane_a + (uint32_t)((2 * wm) * 2048);             // my first token block
+  const uint32_t wa = lane_a + (uint32_t)(8 * 1024 + (3 * wn) * 2048);  // my first feature block
+  // Software pipeline by one stage: after barrier(s) the operands of stage s are READ into one register set
+  // while the MFMAs of stage s-1 run on the other -- the LDS latency (and the LDS-DMA issues of stage s+3)
+  // sit under 24 MFMAs instead of in front of them.
+  auto read_stage = [&](int s, rf_u32x4 (&xb)[4], rf_u32x4 (&wf)[6]) __attribute__((always_inline)) {
+    const uint32_t sb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)(slots + (s % GT_SLOTS) * GT_STAGE_FRAGS * 64);
+    // tile tt of my tokens = block tt >> 1, row group tt & 1; tile ft of my features likewise
+    asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(xb[0]) : "v"(sb + xa));
+    asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(xb[1]) : "v"(sb + xa));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(xb[2]) : "v"(sb + xa));
+    asm volatile("ds_read_b128 %0, %1 offset:2304" : "=v"(xb[3]) : "v"(sb + xa));
+    asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(wf[0]) : "v"(sb + wa));
+    asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(wf[1]) : "v"(sb + wa));
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(wf[2]) : "v"(sb + wa));
+    asm volatile("ds_read_b128 %0, %1 offset:2304" : "=v"(wf[3]) : "v"(sb + wa));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(wf[4]) : "v"(sb + wa));
+    asm volatile("ds_read_b128 %0, %1 offset:4352" : "=v"(wf[5]) : "v"(sb + wa));
+  };
+  auto mfma_stage = [&](rf_u32x4 (&xb)[4], rf_u32x4 (&wf)[6]) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ft = 0; ft < 6; ++ft)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        acc[ft][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wf[ft]), __builtin_bit_cast(half8, xb[tt]),
+                                                             acc[ft][tt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto sync_stage = [&]() __attribute__((always_inline)) {
+    // my pieces of the stage have landed (those of the next two stages may stay in flight) ...
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // ... after the barrier everybody's have, and everybody has READ the previous stage (its slot is free)
+    __builtin_amdgcn_s_barrier();
+  };
+  rf_u32x4 xb0[4], wf0[6], xb1[4], wf1[6];
+  static_assert(NST % 2 == 0, "stages are processed in pairs");
+  sync_stage();
+  read_stage(0, xb0, wf0);
+  issue_stage(3);
+#pragma unroll 1
+  for (int s = 1; s < NST; s += 2) {
+    // odd stage s: read into set 1, compute stage s-1 from set 0
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb0[0]), "+v"(xb0[1]), "+v"(xb0[2]), "+v"(xb0[3]), "+v"(wf0[0]), "+v"(wf0[1]),
+                 "+v"(wf0[2]), "+v"(wf0[3]), "+v"(wf0[4]), "+v"(wf0[5]));
+    sync_stage();
+    read_stage(s, xb1, wf1);
+    issue_stage(s + 3);
+    mfma_stage(xb0, wf0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb1[0]), "+v"(xb1[1]), "+v"(xb1[2]), "+v"(xb1[3]), "+v"(wf1[0]), "+v"(wf1[1]),
+                 "+v"(wf1[2]), "+v"(wf1[3]), "+v"(wf1[4]), "+v"(wf1[5]));
+    if (s + 1 < NST) {   // even stage s+1: read into set 0, compute stage s from set 1
+      sync_stage();
+      read_stage(s + 1, xb0, wf0);
+      issue_stage(s + 4);
+    }
+    mfma_stage(xb1, wf1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump pieces must land before the LDS is handed on
+
+  // ---- epilogue: acc[ft][tt][j] = Y[t0 + 64 wm + 16 tt + c16][n0 + 96 wn + 16 ft + 4 g + j] ----------------
+  const int fbase = n0 + 96 * wn + 4 * g;
+  float mu[4], rstd[4];
+#pragma unroll
+  for (int ft = 0; ft < 6; ++ft) {
+    const half4 bv = *(const half4*)(bias + fbase + 16 * ft);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          f32x2 y;
+          y[0] = acc[ft][tt][j] + (float)bv[j];
+          y[1] = acc[ft][tt][j + 1] + (float)bv[j + 1];
+          y = gelu_erf2(y);
+          acc[ft][tt][j] = y[0];
+          acc[ft][tt][j + 1] = y[1];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[ft][tt][j] += (float)bv[j];
+      }
+      if (EPI == EPI_BIAS_RES_LN) {
+        const half4 rv = *(const half4*)(res + toff(t0 + 64 * wm + 16 * tt + c16, fbase + 16 * ft, HID / 16));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[ft][tt][j] += (float)rv[j];
+      }
+    }
+  }
+  if (EPI == EPI_BIAS_RES_LN) {
+    // LayerNorm over the 384 features of a token: 24 per lane, x 4 lane groups (g), x 4 feature quarters
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 6; ++ft)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = pass ? acc[ft][tt][j] - mu[tt] : acc[ft][tt][j];
+            sum += pass ? d * d : d;
+          }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (g == 0) red[(pass * 4 + wn) * GT_TOK + 64 * wm + 16 * tt + c16] = sum;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int tk = 64 * wm + 16 * tt + c16;
+        const float tot = (red[(pass * 4 + 0) * GT_TOK + tk] + red[(pass * 4 + 1) * GT_TOK + tk]) +
+                          (red[(pass * 4 + 2) * GT_TOK + tk] + red[(pass * 4 + 3) * GT_TOK + tk]);
+        if (pass == 0) mu[tt] = tot * (1.f / HID);
+        else rstd[tt] = rsqrtf(tot * (1.f / HID) + eps);
+      }
+    }
+  }
+#pragma unroll
+  for (int ft = 0; ft < 6; ++ft) {
+    half4 gv, be;
+    if (EPI == EPI_BIAS_RES_LN) {
+      gv = *(const half4*)(gamma + fbase + 16 * ft);
+      be = *(const half4*)(beta + fbase + 16 * ft);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int token = t0 + 64 * wm + 16 * tt + c16;
+      half4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = acc[ft][tt][j];
+        if (EPI == EPI_BIAS_RES_LN) v = (v - mu[tt]) * rstd[tt] * (float)gv[j] + (float)be[j];
+        o[j] = (_Float16)v;
+      }
+      if (token < M) *(half4*)(out + toff(token, fbase + 16 * ft, ldo / 16)) = o;
+    }
+  }
+}
+
 // LayerNorm of ONE fp32 row [384] -> fp16 tiled activations, by one wave
 __device__ __forceinline__ void ln_row(const float* __restrict__ pre, int token, int lane,
                                        const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
@@ -1117,6 +1336,21 @@ static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Floa
       hipLaunchKernelGGL((k_linear_small<E, 96>), grid, dim3(256), 0, st, X, Wt, bias, out, pre, N, m_ptr, res);
     if (EPI == EPI_BIAS_RES_LN)
       hipLaunchKernelGGL(k_ln_rows, dim3((tokens + 3) / 4), dim3(256), 0, st, pre, m_ptr, g, b, eps, out);
+    return;
+  }
+  // bit per GEMM of a layer: 1 = FFN2 + LayerNorm (K 1536), 2 = out-projection + LayerNorm, 4 = QKV, 8 = FFN1
+  const int gt_bit = (K != 384) ? 1 : (EPI == EPI_BIAS_RES_LN ? 2 : (EPI == EPI_BIAS ? 4 : 8));
+  if ((rf_knob_gemm_tile & gt_bit) && tokens >= 8192) {
+    const size_t lds = (size_t)GT_SLOTS * GT_STAGE_FRAGS * RF_FRAG_BYTES + RF_FRAG_BYTES + (size_t)2 * 4 * GT_TOK * 4;
+    const dim3 grid((tokens + GT_TOK - 1) / GT_TOK, N / 384);
+    static rf_lds_attr attr[2];
+    if (K == 384) {
+      (void)rf_ensure_lds(attr[0], (const void*)k_gemm_tile<EPI, 24>, lds);
+      hipLaunchKernelGGL((k_gemm_tile<EPI, 24>), grid, dim3(512), lds, st, X, Wt, bias, out, N, m_ptr, res, g, b, eps);
+    } else {
+      (void)rf_ensure_lds(attr[1], (const void*)k_gemm_tile<EPI, 96>, lds);
+      hipLaunchKernelGGL((k_gemm_tile<EPI, 96>), grid, dim3(512), lds, st, X, Wt, bias, out, N, m_ptr, res, g, b, eps);
+    }
     return;
   }
   if (K == 384 && EPI != EPI_BIAS_RES_LN && rf_knob_linear_dma && tokens >= 8192) {

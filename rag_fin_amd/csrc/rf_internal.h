@@ -59,6 +59,7 @@ RF_KNOB(rf_knob_linear_dma, 1)         // encoder: K = 384 plain-epilogue GEMMs 
 RF_KNOB(rf_knob_linear_small, 1)       // encoder: feature-split GEMMs + separate LayerNorm at <= 1024 token slots
 RF_KNOB(rf_knob_k384_ntb, 4)           // encoder: token blocks per workgroup of the K = 384 LayerNorm GEMM at large batch
 RF_KNOB(rf_knob_ffn2_ntb, 4)           // encoder: the same for the K = 1536 LayerNorm GEMM
+RF_KNOB(rf_knob_gemm_tile, 3)          // encoder: GEMMs on k_gemm_tile (both operands through the LDS-DMA ring): 1 FFN2, 2 out-proj, 4 QKV, 8 FFN1
 RF_KNOB(rf_knob_encode_graph, 1)       // encoder: query-sized forwards replay a cached hipGraph
 RF_KNOB(rf_knob_linear_dbg, 0)         // encoder: k_linear_dma ablation bits (results wrong)
 RF_KNOB(rf_knob_debug_epi, 1)          // encoder: which k_linear_dma epilogue writes clock stamps

@@ -111,10 +111,16 @@ def load_library() -> ctypes.CDLL:
     path = library_path()
     in_tree = path in (_build.LIB_PATH, _build.EXP_LIB_PATH)
     exp = path == _build.EXP_LIB_PATH
-    if in_tree and _build.have_hipcc():
-        _build.build_lib(experiments=exp)   # no-op when objects and digest are current
+    if in_tree and (not os.path.exists(path) or _build.built_digest(path) != _build.source_digest(exp)):
+        # missing, or built from other sources than those on disk: rebuild where hipcc exists, refuse
+        # where it does not -- no fallback.  A current library is loaded as it is: no compiler runs at import.
+        if not _build.have_hipcc():
+            raise RuntimeError(f"{path} is missing or was built from other sources (build id "
+                               f"{_build.built_digest(path) or 'none'}, sources {_build.source_digest(exp)}) and hipcc is "
+                               "not available to rebuild it; run `python -m rag_fin_amd.build` where the ROCm toolchain is")
+        _build.build_lib(experiments=exp)
     elif not os.path.exists(path):
-        _build.build_lib(experiments=exp)   # raises: hipcc is missing -- no fallback
+        raise RuntimeError(f"{path} does not exist")
     # torch ships its own libamdhip64; load it FIRST so that this library binds to the
     # same HIP runtime instance (loaded the other way round, the two runtimes disagree
     # about device visibility: rf_device_check saw "no HIP device" on a GPU box)

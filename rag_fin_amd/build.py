@@ -105,7 +105,17 @@ def build_lib(force: bool = False, verbose: bool = False, experiments: bool = Fa
         relink = True
     if relink:
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, id_obj])
+    with open(out + ".id", "w") as f:   # sidecar: lets the loader decide without dlopen-ing a stale library
+        f.write(digest)
     return out
+
+
+def built_digest(path: str) -> str:
+    try:
+        with open(path + ".id") as f:
+            return f.read().strip()
+    except OSError:
+        return ""
 
 
 if __name__ == "__main__":

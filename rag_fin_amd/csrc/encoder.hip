@@ -1281,39 +1281,71 @@ __global__ void __launch_bounds__(256) k_attention(const _Float16* __restrict__ 
   }
 }
 
-// masked mean over the sequence (all packed rows are valid), clamp(count, 1e-9),
-// then x / max(||x||, 1e-12).  One workgroup (192 threads x 2 features) per sequence.
-__global__ void __launch_bounds__(192) k_pool_norm(const _Float16* __restrict__ x,
+// masked mean over the sequence (all packed rows are valid), clamp(count, 1e-9), then
+// x / max(||x||, 1e-12).  One 4-wave workgroup per sequence.  The activations are fragment-tiled
+// (32 tokens x 16 features = 1 KiB contiguous), so a wave reads whole fragments: wave w takes the
+// feature steps kk = w, w + 4, ... of every token block the sequence touches, lane (t = l & 31,
+// h = l >> 5) adds the 8 features 16 kk + 8 h .. of token 32 tb + t, and the 32 token lanes meet in
+// a shuffle tree.  (Round 1 walked the rows one by one with 2-byte loads: 50 us per 64 k-token
+// batch, as long as a GEMM.)
+__global__ void __launch_bounds__(256) k_pool_norm(const _Float16* __restrict__ x,
                                                    const int32_t* __restrict__ tok_off,
                                                    _Float16* __restrict__ out16,
                                                    float* __restrict__ out32) {
-  __shared__ float red[3];
+  __shared__ float pooled[HID];
+  __shared__ float red[4];
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 31, h = lane >> 5;
   const int r0 = tok_off[b];
   const int n = tok_off[b + 1] - r0;
-  float a0 = 0.f, a1 = 0.f;
-  for (int r = 0; r < n; ++r) {
-    const _Float16* row = x + toff(r0 + r, tid * 2, HID / 16);
-    a0 += (float)row[0];
-    a1 += (float)row[1];
+  const int tb0 = r0 >> 5, tb1 = (r0 + n + 31) >> 5;   // token blocks [tb0, tb1)
+  const float inv_cnt = 1.f / fmaxf((float)n, 1e-9f);
+  for (int kk = wave; kk < HID / 16; kk += 4) {
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    for (int tb = tb0; tb < tb1; ++tb) {
+      const int tok = tb * 32 + t;
+      if (tok >= r0 && tok < r0 + n) {
+        const half8 v = *(const half8*)(x + (((size_t)tb * (HID / 16) + kk) * 64 + lane) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = a[j];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      if (t == 0) pooled[16 * kk + 8 * h + j] = v * inv_cnt;
+    }
   }
-  const float cnt = fmaxf((float)n, 1e-9f);
-  a0 /= cnt;
-  a1 /= cnt;
-  float s = wave_sum(a0 * a0 + a1 * a1);
-  if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
-  const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2]), 1e-12f);
-  a0 /= nrm;
-  a1 /= nrm;
-  if (out16) {
-    out16[(size_t)b * HID + tid * 2] = (_Float16)a0;
-    out16[(size_t)b * HID + tid * 2 + 1] = (_Float16)a1;
+  float a0 = 0.f, a1 = 0.f;
+  if (tid < HID / 2) {
+    a0 = pooled[tid * 2];
+    a1 = pooled[tid * 2 + 1];
   }
-  if (out32) {
-    out32[(size_t)b * HID + tid * 2] = a0;
-    out32[(size_t)b * HID + tid * 2 + 1] = a1;
+  const float s = wave_sum(a0 * a0 + a1 * a1);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float nrm = fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);
+  if (tid < HID / 2) {
+    a0 /= nrm;
+    a1 /= nrm;
+    if (out16) {
+      out16[(size_t)b * HID + tid * 2] = (_Float16)a0;
+      out16[(size_t)b * HID + tid * 2 + 1] = (_Float16)a1;
+    }
+    if (out32) {
+      out32[(size_t)b * HID + tid * 2] = a0;
+      out32[(size_t)b * HID + tid * 2 + 1] = a1;
+    }
   }
 }
 
@@ -1522,7 +1554,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
                                    tiles, m_ptr, y, (const _Float16*)w.ln2_g + (size_t)l * HID,
                                    (const _Float16*)w.ln2_b + (size_t)l * HID, c.ln_eps, ws.pre, st);
   }
-  hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(192), 0, st, x, ws.tok_off, (_Float16*)out_f16_dev,
+  hipLaunchKernelGGL(k_pool_norm, dim3(B), dim3(256), 0, st, x, ws.tok_off, (_Float16*)out_f16_dev,
                      out_f32_dev);
   RF_HIP(hipGetLastError());
   return RF_OK;

@@ -35,7 +35,7 @@ def main():
                 vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     per = {}
     for kname, counters in vals.items():
-        if not any(t in kname for t in ("k_scan", "k_merge", "k_threshold", "k_linear", "k_attention", "k_embed", "k_pool")):
+        if not any(t in kname for t in ("k_scan", "k_merge", "k_threshold", "k_linear", "k_gemm", "k_attention", "k_embed", "k_pool")):
             continue
         rec = {}
         for cname, xs in counters.items():
@@ -60,6 +60,14 @@ def main():
         if busy and gui:
             # SQ counters sum over the SIMDs that ran waves; GRBM_GUI_ACTIVE sums the 8 XCDs
             out["mfma_busy_frac"] = round(busy / (gui / 8.0 * 1024.0), 4)
+    # matrix-pipe utilisation of every kernel that issued MFMAs (busy cycles / (GPU-active cycles x 1024 SIMDs))
+    util = {}
+    for kname, rec in per.items():
+        busy, gui = rec.get("SQ_VALU_MFMA_BUSY_CYCLES"), rec.get("GRBM_GUI_ACTIVE")
+        if busy and gui:
+            util[kname] = {"mfma_busy_frac": round(busy / (gui / 8.0 * 1024.0), 4),
+                           "valu_insts_per_mfma_incl_mfma": round(rec.get("SQ_INSTS_VALU", 0) / max(rec.get("SQ_INSTS_MFMA", 1), 1), 3)}
+    out["mfma_utilisation"] = util
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps({k: out.get(k) for k in ("kernel", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch",
                                                "mfma_busy_frac")}))

@@ -1076,7 +1076,12 @@ __device__ __forceinline__ float att_max3(float a, float b, float c) {
 }
 #define ATT_MAX_KB 8
 #define ATT_HEADS 2   // heads per workgroup (12 heads -> grid.y = 6)
-__global__ void __launch_bounds__(256, 2) k_attention_mfma(const _Float16* __restrict__ qkv,
+// KB = key blocks of 32 the instantiation holds scores for (2 | 4 | 6 | 8: T <= 64 | 128 | 192 | 256).  The
+// scores of a (query block, head) item stay in registers between the two products -- 16 KB registers -- and
+// the kernel is latency-bound (10 % matrix pipe busy), so short batches (the ingest buckets are sorted by
+// length) take an instantiation with fewer registers and more waves per SIMD instead of the T = 256 one.
+template <int KB, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __restrict__ qkv,
                                                         const int32_t* __restrict__ tok_off,
                                                         _Float16* __restrict__ ctx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1127,10 +1132,10 @@ __global__ void __launch_bounds__(256, 2) k_attention_mfma(const _Float16* __res
       if (q0 + c < n)
         qf[s] = *(const half8*)(qkv + toff(r0 + q0 + c, head * HEAD_DIM + 16 * s + 8 * h, 3 * HID / 16));
     }
-    f32x16 sc[ATT_MAX_KB];
+    f32x16 sc[KB];
     float m = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < ATT_MAX_KB; ++kb) {
+    for (int kb = 0; kb < KB; ++kb) {
       if (kb < nkb) {
         f32x16 acc;
 #pragma unroll
@@ -1163,7 +1168,7 @@ __global__ void __launch_bounds__(256, 2) k_attention_mfma(const _Float16* __res
     const float c2 = scale * 1.4426950408889634f;   // exp(scale * (s - m)) = exp2(c2 * s - c2 * m)
     const float mc = m * c2;
 #pragma unroll
-    for (int kb = 0; kb < ATT_MAX_KB; ++kb) {
+    for (int kb = 0; kb < KB; ++kb) {
       if (kb < nkb) {
         // exponent argument and row sum on PAIRS (v_pk_fma_f32 / v_pk_add_f32: two floats per
         // lane at the single rate); v_exp_f32 is the transcendental pipe either way
@@ -1188,7 +1193,7 @@ __global__ void __launch_bounds__(256, 2) k_attention_mfma(const _Float16* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < ATT_MAX_KB; ++kb) {
+    for (int kb = 0; kb < KB; ++kb) {
       if (kb < nkb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -1525,11 +1530,16 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
                        (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
   }
   const size_t attn_lds = (size_t)T * 2 * HEAD_DIM * 2;
-  static rf_lds_attr attn_attr, mfma_attr;
+  static rf_lds_attr attn_attr;
   if (T > 32 * ATT_MAX_KB) RF_HIP(rf_ensure_lds(attn_attr, (const void*)k_attention, attn_lds));
   const int tpad_max = (T + 31) / 32 * 32;
   const size_t mfma_lds = ATT_HEADS * ((size_t)tpad_max * 80 + (size_t)32 * (tpad_max + 4) * 2);  // 74 KB at T = 256
-  if (T <= 32 * ATT_MAX_KB) RF_HIP(rf_ensure_lds(mfma_attr, (const void*)k_attention_mfma, mfma_lds));
+  // instantiation by the batch's width: <key blocks, minimum waves per SIMD the register budget must allow>
+  const int att_kb = T <= 64 ? 2 : (T <= 128 ? 4 : (T <= 192 ? 6 : 8));
+  const void* att_fn = att_kb == 2 ? (const void*)k_attention_mfma<2, 4> : att_kb == 4 ? (const void*)k_attention_mfma<4, 3>
+                     : att_kb == 6 ? (const void*)k_attention_mfma<6, 2> : (const void*)k_attention_mfma<8, 2>;
+  static rf_lds_attr mfma_attrs[4];
+  if (T <= 32 * ATT_MAX_KB) RF_HIP(rf_ensure_lds(mfma_attrs[att_kb / 2 - 1], att_fn, mfma_lds));
   _Float16* x = ws.x;
   _Float16* y = ws.y;
   for (int l = 0; l < L; ++l) {
@@ -1539,9 +1549,13 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
     const uint4* ff2_t = enc->ff2_t + (size_t)l * HID * I / 8;
     launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
                             3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
-    if (T <= 32 * ATT_MAX_KB)
-      hipLaunchKernelGGL(k_attention_mfma, dim3(B, c.heads / ATT_HEADS), dim3(256), mfma_lds, st, ws.qkv,
-                         ws.tok_off, ws.ctx);
+    if (T <= 32 * ATT_MAX_KB) {
+      const dim3 ag(B, c.heads / ATT_HEADS);
+      if (att_kb == 2) hipLaunchKernelGGL((k_attention_mfma<2, 4>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx);
+      else if (att_kb == 4) hipLaunchKernelGGL((k_attention_mfma<4, 3>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx);
+      else if (att_kb == 6) hipLaunchKernelGGL((k_attention_mfma<6, 2>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx);
+      else hipLaunchKernelGGL((k_attention_mfma<8, 2>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx);
+    }
     else
       hipLaunchKernelGGL(k_attention, dim3(B, c.heads), dim3(256), attn_lds, st, ws.qkv, ws.tok_off,
                          ws.ctx);

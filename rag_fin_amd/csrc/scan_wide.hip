@@ -1,22 +1,18 @@
 // Wide sweep: up to 256 queries against the corpus in ONE pass (dim 384).
 //
-// The 64-query kernel (scan.hip) keeps the queries in LDS and streams corpus
-// fragments straight into registers; at 256 queries the roles flip:
-//   * each of the 8 waves of a workgroup owns 32 queries and keeps their 24 B-operand
-//     fragments in REGISTERS for the whole sweep (96 VGPRs, loaded once);
-//   * a corpus block (32 rows, 24 KiB) is brought from HBM ONCE per workgroup and
-//     shared by the 8 waves through LDS: wave w loads fragments 3w..3w+2 into
-//     registers three blocks ahead (72 KiB in flight per CU), writes them to the
-//     current LDS slot, one barrier, then every wave reads all 24 fragments
-//     (linear 1-KiB images: conflict-free ds_read_b128) and runs 24 MFMAs.
-// Arithmetic intensity is 256 flop per corpus byte: at the HBM rate the matrix pipe
-// must run at ~2/3 of its peak, so this is the configuration where HBM and MFMA are
-// both near their roofs (BASELINE.json configs[2], "HBM-roofline run").
-// The lane-local filter, the sample/emit modes and the candidate lists are the ones
-// of scan.hip (one query block per wave).
-// Tried and dropped: every wave streaming the corpus itself through a register ring (no
-// LDS, no barrier; 7 of 8 reads are L1/L2 hits) -- 447 us per 256-query step against
-// 284 us for this form: the 8x load-instruction count saturates the TA path.
+// The 64-query kernel (scan.hip) keeps the queries in LDS and streams corpus fragments straight
+// into registers; at 256 queries the roles flip:
+//   * each of the 8 waves of a workgroup owns 32 queries and keeps them as B-operand fragments in
+//     REGISTERS for the whole sweep (96 VGPRs, loaded once);
+//   * a corpus block (32 rows, 24 KiB) is brought from HBM ONCE per workgroup by LDS-DMA into a
+//     3-slot ring of 2-block phases and shared by the 8 waves through LDS.
+// Arithmetic intensity is 256 flop per corpus byte: HBM and the matrix pipe are both near their
+// roofs (BASELINE.json configs[2], "HBM-roofline run").  The product kernel is k_scan_w16 below
+// (round 2: v_mfma_f32_16x16x32_f16, unequal wave halves, priority by progress); the round-1 kernel
+// k_scan_ldsdma (32x32x16, waves in lockstep) is compiled into the experiments build only, as the
+// A/B arm of tools/bench_wide.py.  DESIGN.md 4.1b has the measurements and the forms that were
+// tried and dropped (register-staged ring, 4 waves x 64 queries, every wave streaming the corpus
+// itself: 447 us per step -- 8x the load instructions saturate the TA path).
 #include "scan_common.h"
 #include "lds_ring.h"
 #include <stdlib.h>

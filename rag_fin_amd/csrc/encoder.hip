@@ -509,10 +509,37 @@ __global__ void __launch_bounds__(256) k_linear(
 // two feature blocks; WIDE = 1: 256 tokens per workgroup, every wave owns a token block and takes
 // BOTH feature blocks of a phase (the per-wave fixed costs -- six LDS-DMA issues, a barrier --
 // are paid once per 48 MFMAs instead of once per 24, and a weight byte serves 256 tokens).
-template <int EPI, int WIDE>
-__global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
+// GELU for the deferred epilogue below: plain (unpacked) fp32 only.  Measured on gfx950
+// (tools/ubench/mfma_valu.hip): v_fma_f32 issues under the MFMAs of either wave of the SIMD at
+// almost no cost (8 MFMA + 32 v_fma_f32 in one wave: 276 cycles against 264 for the MFMAs alone),
+// v_pk_fma_f32 does not (484 cycles) -- the packed form is only worth its two lanes where no MFMA
+// is in flight.  h(y) = y (1/2 + yc Q(t)), yc = y clamped to +-3.2 sqrt 2, t = yc^2 / 3.2^2 - 1:
+// the erf polynomial of gelu_erf2 with 1/(2 sqrt 2) folded into its coefficients; 16 VALU
+// operations per value (bias add included), same error (2e-5 absolute at the clamp).
+__device__ __forceinline__ float gelu_erf_s(float y) {
+  constexpr float CP = 4.52548360824585f;   // 3.2 sqrt 2
+  const float yc = __builtin_amdgcn_fmed3f(y, -CP, CP);
+  const float t = __builtin_fmaf(yc * yc, 0.09765625f, -1.f);
+  float p = __builtin_fmaf(t, 8.469007444e-04f, -2.387454268e-03f);
+  p = __builtin_fmaf(t, p, 3.280109027e-03f);
+  p = __builtin_fmaf(t, p, -5.588355009e-03f);
+  p = __builtin_fmaf(t, p, 1.136882324e-02f);
+  p = __builtin_fmaf(t, p, -1.921003498e-02f);
+  p = __builtin_fmaf(t, p, 2.861942165e-02f);
+  p = __builtin_fmaf(t, p, -4.021260887e-02f);
+  p = __builtin_fmaf(t, p, 5.456056446e-02f);
+  p = __builtin_fmaf(t, p, -7.682786137e-02f);
+  p = __builtin_fmaf(t, p, 1.560353935e-01f);
+  return y * __builtin_fmaf(yc, p, 0.5f);
+}
+
+// ABL: ablations for tools/bench_encode.py --linear-dbg (experiments build only; results wrong):
+// 1 = every LDS-DMA piece re-reads one cached KiB, 2 = no LDS-DMA in the loop, 4 = no epilogue,
+// 8 = every workgroup stores into one L2-resident window, 16 = no LDS fragment reads, 32 = no MFMAs.
+template <int EPI, int WIDE, int ABL>
+__global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-packed-fp32-ops"))) k_linear_dma(
     const _Float16* __restrict__ X, const uint4* __restrict__ Wt, const _Float16* __restrict__ bias,
-    _Float16* __restrict__ out, int N, const int32_t* __restrict__ m_ptr, float* __restrict__ dbg, int dbg_flags) {
+    _Float16* __restrict__ out, int N, const int32_t* __restrict__ m_ptr, float* __restrict__ dbg) {
   constexpr int KS = HID / 16;   // 24
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // diagnostic run only (dbg != nullptr, tools/bench_encode.py --stamps): clock stamps per wave
@@ -521,7 +548,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
   uint64_t ts_loop = 0, t_wait = 0;
   rf_u32x4* slots = (rf_u32x4*)smem_raw;                      // [3][48 * 64]
   rf_u32x4* const dump = slots + LD_SLOTS * LD_FRAGS * 64;    // 1 KiB
-  _Float16* bias_l = (_Float16*)(dump + 64);                  // [N]
+  float* bias_l = (float*)(dump + 64);                        // [N] as fp32
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -536,7 +563,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
     rf_u32x4* dst;
     int dstep, sstep;
   };
-  auto pieces_of = [&](uint32_t ph) {
+  auto pieces_of = [&](uint32_t ph) __attribute__((always_inline)) {
     const bool live = ph < n_ph;
     uint32_t b = 2u * ph + (uint32_t)(wave >> 2);
     b = live ? b : nblk - 1u;
@@ -545,13 +572,13 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
     pc.dst = live ? slots + ((ph % LD_SLOTS) * LD_FRAGS + wave * LD_PW) * 64 : dump;
     pc.dstep = live ? 64 : 0;
     pc.sstep = 64;
-    if (dbg_flags & 1) {   // ablation (wrong results): every piece re-reads one cached KiB
+    if (ABL & 1) {
       pc.src = Wt + lane;
       pc.sstep = 0;
     }
     return pc;
   };
-  auto issue_piece = [&](const Pieces& pc, int j) {
+  auto issue_piece = [&](const Pieces& pc, int j) __attribute__((always_inline)) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pc.src + j * pc.sstep),
                                      (__attribute__((address_space(3))) void*)(pc.dst + j * pc.dstep), 16, 0, 0);
   };
@@ -577,7 +604,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
-  for (int i = tid; i < N / 8; i += LD_WAVES * 64) *(uint4*)(bias_l + i * 8) = *(const uint4*)(bias + i * 8);
+  for (int i = tid; i < N; i += LD_WAVES * 64) bias_l[i] = (float)bias[i];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
     rf_u32x4 v = xf[kk];
@@ -587,98 +614,138 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) k_linear_dma(
   __syncthreads();   // bias in LDS (this barrier also drains the first DMA pieces: needed at once anyway)
 
   // lane's slot in the tiled output: token block (t0/32 + tb), feature 4 h, lane c (see toff())
-  _Float16* const out_lane = out + (((size_t)(t0 >> 5) + tb) * (size_t)(N / 16) * 64 + c) * 8 + 4 * h;
-  const uint32_t bias_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)bias_l + (uint32_t)h * 8u;
-  f32x16 acc;
-  // matrix part of a phase: this wave's feature block (par) of the slot x its 32 tokens
-  auto mfma_part = [&](uint32_t ph, const Pieces& nxt, int par, bool with_dma) {
+  _Float16* const out_lane = out + (((ABL & 8) ? (size_t)tb : ((size_t)(t0 >> 5) + tb)) * (size_t)(N / 16) * 64 + c) * 8 + 4 * h;
+  // lane's 16 features of a block: 8 g + 4 h + j -> four 16-byte reads of the fp32 bias
+  const uint32_t bias_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)bias_l + (uint32_t)h * 16u;
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  struct Bias {
+    f32x4v q[4];
+  };
+  auto bias_issue = [&](Bias& bq, uint32_t blk) __attribute__((always_inline)) {
+    const uint32_t ba = bias_a + blk * 128u;
+    asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(bq.q[0]) : "v"(ba));
+    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(bq.q[1]) : "v"(ba));
+    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(bq.q[2]) : "v"(ba));
+    asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(bq.q[3]) : "v"(ba));
+  };
+  auto bias_landed = [&](Bias& bq) __attribute__((always_inline)) {   // call after a wait that covers the four reads
+    asm volatile("" : "+v"(bq.q[0]), "+v"(bq.q[1]), "+v"(bq.q[2]), "+v"(bq.q[3]));
+  };
+  // epilogue of one finished block: acc[4 g + j] = Y[token][32 blk + 8 g + 4 h + j], in four quads
+  // (quad g = one 8-byte store).  Four values = four independent dependency chains: a dependent
+  // v_fma_f32 issues every ~8 cycles, four interleaved chains every ~5.3 (tools/ubench/mfma_valu2.hip).
+  auto epi_quad = [&](const f32x16& acc, const Bias& bq, uint32_t blk, int g) __attribute__((always_inline)) {
+    if (ABL & 4) return;
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = acc[4 * g + j] + bq.q[g][j];
+    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = gelu_erf_s(y[j]);
+    }
+    const half4 o = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+    // unconditional: rows >= M of the last tile exist (the workspace is padded to whole tiles) and
+    // nobody reads them -- and a fixed 4 stores per block keeps the vmcnt arithmetic exact.
+    // toff(token, 32 blk + 8 g + 4 h) = per-lane base + a wave-uniform offset:
+    *(half4*)(out_lane + ((size_t)((ABL & 8) ? (blk & 1u) : blk) * 2 + (g >> 1)) * 512 + (g & 1) * 256) = o;
+  };
+  auto epilogue = [&](const f32x16& acc, const Bias& bq, uint32_t blk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) epi_quad(acc, bq, blk, g);
+  };
+  // matrix part of a phase: this wave's feature block (par) of the slot x its 32 tokens.  In the WIDE
+  // form the epilogue of the PREVIOUS block (prev, blk_prev) is cut into the same instruction stream:
+  // after every sixth MFMA one quad of outputs (~70 plain VALU operations), fenced with sched_barrier so
+  // that the compiler keeps the slices where they are -- the VALU work issues under the MFMAs (of this
+  // wave and of the other wave of the SIMD) instead of in a VALU-only stretch between two MFMA stretches.
+  auto mfma_part = [&](uint32_t ph, const Pieces& nxt, int par, bool with_dma, f32x16& acc, const f32x16* prev,
+                       uint32_t blk_prev) __attribute__((always_inline)) {
     const rf_u32x4* slot = slots + ((ph % LD_SLOTS) * LD_FRAGS + par * KS) * 64 + lane;
     const uint32_t sa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)slot;
     rf_u32x4 fa[2][WL_GRP];
     constexpr int NG = KS / WL_GRP;   // 6
-    lds_read_group<0>(fa[0], sa);
+    Bias bq;
+    if (prev) bias_issue(bq, blk_prev);   // older than every fragment read of this part: covered by its first wait
+    if (!(ABL & 16)) lds_read_group<0>(fa[0], sa);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g + 1 < NG) {
-        lds_read_group_dyn(fa[(g + 1) & 1], sa, (g + 1) * WL_GRP);
-        lds_wait_group<WL_GRP>(fa[g & 1]);
-      } else {
-        lds_wait_group<0>(fa[g & 1]);
-      }
-      if (with_dma && g < LD_PW && !(dbg_flags & 2)) issue_piece(nxt, g);   // one LDS-DMA piece per group of 4 MFMAs
-#pragma unroll
-      for (int j = 0; j < WL_GRP; ++j) {
-        const int kk = g * WL_GRP + j;
-        const half8 a = __builtin_bit_cast(half8, fa[g & 1][j]);
-        if (kk == 0) {
-          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), z, 0, 0, 0);
+    for (int kk = 0; kk < KS; ++kk) {
+      const int g = kk / WL_GRP, j = kk % WL_GRP;
+      if (j == 0) {
+        if (ABL & 16) {   // no fragment reads (the bias reads still need their wait)
+          if (g == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (g + 1 < NG) {
+          lds_read_group_dyn(fa[(g + 1) & 1], sa, (g + 1) * WL_GRP);
+          lds_wait_group<WL_GRP>(fa[g & 1]);
         } else {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), acc, 0, 0, 0);
+          lds_wait_group<0>(fa[g & 1]);
         }
+        if (prev && g == 0) bias_landed(bq);
+        if (with_dma && g < LD_PW && !(ABL & 2)) issue_piece(nxt, g);   // one LDS-DMA piece per group of 4 MFMAs
       }
-    }
-  };
-  // epilogue of one finished block: acc[4 g + j] = Y[token][32 blk + 8 g + 4 h + j]
-  auto epilogue = [&](uint32_t blk) {
-    uint2 bq[4];
-    const uint32_t ba = bias_a + blk * 64u;   // bias of the lane's 16 features
-    asm volatile("ds_read_b64 %0, %1 offset:0" : "=v"(bq[0]) : "v"(ba));
-    asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(bq[1]) : "v"(ba));
-    asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(bq[2]) : "v"(ba));
-    asm volatile("ds_read_b64 %0, %1 offset:48" : "=v"(bq[3]) : "v"(ba));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const half4 bv = __builtin_bit_cast(half4, bq[g]);
-      half4 o;
-      if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-          f32x2 y;
-          y[0] = acc[4 * g + j] + (float)bv[j];
-          y[1] = acc[4 * g + j + 1] + (float)bv[j + 1];
-          y = gelu_erf2(y);
-          o[j] = (_Float16)y[0];
-          o[j + 1] = (_Float16)y[1];
-        }
+      const half8 a = __builtin_bit_cast(half8, fa[g & 1][j]);
+      if (ABL & 32) {   // no MFMAs
+        if (kk == 0) asm volatile("" : "=v"(acc));
+      } else if (kk == 0) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), z, 0, 0, 0);
       } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (_Float16)(acc[4 * g + j] + (float)bv[j]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), acc, 0, 0, 0);
       }
-      // unconditional: rows >= M of the last tile exist (the workspace is padded to whole tiles) and
-      // nobody reads them -- and a fixed 4 stores per phase keeps the vmcnt arithmetic exact.
-      // toff(token, 32 blk + 8 g + 4 h) = per-lane base + a wave-uniform offset:
-      *(half4*)(out_lane + ((size_t)blk * 2 + (g >> 1)) * 512 + (g & 1) * 256) = o;
+      if (prev && kk % 6 == 5) {
+        epi_quad(*prev, bq, blk_prev, kk / 6);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   if (dbg) ts_loop = __builtin_amdgcn_s_memtime();
-  for (uint32_t ph = 0; ph < n_ph; ++ph) {
-    uint64_t ts0 = 0;
-    if (dbg) ts0 = __builtin_amdgcn_s_memtime();
-    // the previous phase issued, after the barrier that follows my pieces of phase ph, exactly 6
-    // pieces (phase ph+1) and 4 stores (8 in the WIDE form): those may stay in flight, everything
-    // older has landed
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + (WIDE ? 8 : 4)) : "memory");
-    __builtin_amdgcn_s_barrier();
-    if (dbg) t_wait += __builtin_amdgcn_s_memtime() - ts0;
-    const Pieces nxt = pieces_of(ph + 2);
-    // Tried and dropped: running the two waves of a SIMD (w and w + 4) through the phase in
-    // OPPOSITE orders (one's MFMAs over the other's epilogue and DMA issues, pieces issued in a
-    // burst): 5 300 cycles per phase instead of 4 300 -- a burst of six LDS-DMA issues costs more
-    // than six issues spread over the MFMA groups.
-    if (WIDE) {
-      mfma_part(ph, nxt, 0, true);
-      if (!(dbg_flags & 4)) epilogue(2u * ph);
-      mfma_part(ph, nxt, 1, false);
-      if (!(dbg_flags & 4)) epilogue(2u * ph + 1u);
-    } else {
+  if (WIDE) {
+    // Block b's epilogue runs under block b + 1's MFMAs.  Before the loop there is no finished block:
+    // the first part "finishes" an all-zero accumulator into block 0's place, which the real block 0
+    // (stored later by the same lanes) overwrites -- no branch in the loop, and the VMEM count per
+    // phase (6 pieces + 8 stores) stays what the counted wait below assumes.
+    f32x16 acc0, acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint32_t ph = 0; ph < n_ph; ++ph) {
+      uint64_t ts0 = 0;
+      if (dbg) ts0 = __builtin_amdgcn_s_memtime();
+      // the previous phase issued, after the barrier that follows my pieces of phase ph, exactly 6
+      // pieces (phase ph+1) and 8 stores: those may stay in flight, everything older has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + 8) : "memory");
+      __builtin_amdgcn_s_barrier();
+      if (dbg) t_wait += __builtin_amdgcn_s_memtime() - ts0;
+      const Pieces nxt = pieces_of(ph + 2);
+      mfma_part(ph, nxt, 0, true, acc0, &acc1, ph ? 2u * ph - 1u : 0u);
+      mfma_part(ph, nxt, 1, false, acc1, &acc0, 2u * ph);
+    }
+    {   // the last block's epilogue has no MFMAs to hide under
+      Bias bq;
+      bias_issue(bq, nblk - 1u);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bias_landed(bq);
+      epilogue(acc1, bq, nblk - 1u);
+    }
+  } else {
+    f32x16 acc;
+    for (uint32_t ph = 0; ph < n_ph; ++ph) {
+      uint64_t ts0 = 0;
+      if (dbg) ts0 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + 4) : "memory");
+      __builtin_amdgcn_s_barrier();
+      if (dbg) t_wait += __builtin_amdgcn_s_memtime() - ts0;
+      const Pieces nxt = pieces_of(ph + 2);
+      // Tried and dropped: running the two waves of a SIMD (w and w + 4) through the phase in
+      // OPPOSITE orders (one's MFMAs over the other's epilogue and DMA issues, pieces issued in a
+      // burst): 5 300 cycles per phase instead of 4 300 -- a burst of six LDS-DMA issues costs more
+      // than six issues spread over the MFMA groups.
       const int par = wave >> 2;
-      mfma_part(ph, nxt, par, true);
-      if (!(dbg_flags & 4)) epilogue(2u * ph + (uint32_t)par);
+      mfma_part(ph, nxt, par, true, acc, nullptr, 0u);
+      Bias bq;
+      bias_issue(bq, 2u * ph + (uint32_t)par);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bias_landed(bq);
+      epilogue(acc, bq, 2u * ph + (uint32_t)par);
     }
   }
-  if (dbg_flags & 4) asm volatile("" : "+a"(acc));
+  if (ABL & 4) asm volatile("" ::"v"(out_lane));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump pieces must land before the LDS is handed on
   if (dbg && lane == 0) {
     float* o = dbg + ((size_t)blockIdx.x * LD_WAVES + wave) * 8;
@@ -1075,95 +1142,161 @@ __device__ __forceinline__ float att_max3(float a, float b, float c) {
   return r;
 }
 #define ATT_MAX_KB 8
-#define ATT_HEADS 2   // heads per workgroup (12 heads -> grid.y = 6)
 // KB = key blocks of 32 the instantiation holds scores for (2 | 4 | 6 | 8: T <= 64 | 128 | 192 | 256).  The
 // scores of a (query block, head) item stay in registers between the two products -- 16 KB registers -- and
 // the kernel is latency-bound (10 % matrix pipe busy), so short batches (the ingest buckets are sorted by
 // length) take an instantiation with fewer registers and more waves per SIMD instead of the T = 256 one.
-template <int KB, int WPS>
+template <int KB, int WPS, int NH>   // NH = heads per workgroup (1 | 2)
 __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __restrict__ qkv,
                                                         const int32_t* __restrict__ tok_off,
-                                                        _Float16* __restrict__ ctx) {
+                                                        _Float16* __restrict__ ctx, float* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  // a workgroup serves ATT_HEADS heads of one sequence: the (head, query block) items are
-  // dealt round-robin to the 4 waves (5 query blocks x 2 heads = 10 items -> 3 rounds
-  // instead of 2 x 2), and the fixed launch / staging latencies are paid once per pair
-  const int b = blockIdx.x, head0 = blockIdx.y * ATT_HEADS;
+  // diagnostic run only (dbg != nullptr, tools/bench_encode.py --stamps --stamp-epi 2): clock stamps per wave
+  const uint64_t ts_entry = dbg ? __builtin_amdgcn_s_memtime() : 0;
+  uint64_t ts_stage = 0, t_qk = 0, t_exp = 0, t_pv = 0, t_out = 0;
+  // a workgroup serves NH heads of one sequence: the (head, query block) items are dealt round-robin to the 4
+  // waves.  NH = 1 is the product's choice: half the LDS per workgroup lets a third workgroup share the CU at
+  // T = 256 (3 waves per SIMD), and the kernel's time is waiting -- staging latency, LDS and MFMA drains -- not
+  // issue: +2 % on the whole encoder against NH = 2 (A/B in one process, tools/bench_encode.py --tune att_heads=).
+  const int b = blockIdx.x, head0 = blockIdx.y * NH;
   const int r0 = tok_off[b];
   const int n = tok_off[b + 1] - r0;
   if (n <= 0) return;
   const int nkb = (n + 31) >> 5;
-  const int tpad = nkb * 32;
-  const int vstride = tpad + 4;
-  const size_t head_lds = (size_t)tpad * 40 + (size_t)32 * vstride;    // halfs per head: K rows, then V^T
+  // the LDS image has the INSTANTIATION's shape (TP = 32 KB rows, zero beyond the sequence): compile-time
+  // strides, and the K Q^T products below need no per-block branch
+  constexpr int TP = KB * 32;
+  constexpr int vstride = TP + 4;
+  constexpr size_t head_lds = (size_t)TP * 40 + (size_t)32 * vstride;    // halfs per head: K rows, then V^T
   _Float16* lds_h = (_Float16*)lds;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 31, h = lane >> 5;
-  for (int i = tid; i < ATT_HEADS * tpad * 4; i += 256) {
-    const int hh = i / (tpad * 4), rem = i % (tpad * 4);
-    const int row = rem >> 2, part = rem & 3;
-    half8 kv, vv;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { kv[e] = (_Float16)0.f; vv[e] = (_Float16)0.f; }
-    if (row < n) {
-      kv = *(const half8*)(qkv + toff(r0 + row, HID + (head0 + hh) * HEAD_DIM + part * 8, 3 * HID / 16));
-      vv = *(const half8*)(qkv + toff(r0 + row, 2 * HID + (head0 + hh) * HEAD_DIM + part * 8, 3 * HID / 16));
-    }
-    _Float16* ks_w = lds_h + hh * head_lds;
-    _Float16* vt_w = ks_w + (size_t)tpad * 40;
-    *(half8*)(ks_w + row * 40 + part * 8) = kv;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) vt_w[(part * 8 + e) * vstride + row] = vv[e];
-  }
-  __syncthreads();
-  const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
-  for (int item = wave; item < ATT_HEADS * nkb; item += 4) {
-    const int head = head0 + item / nkb;
-    const int qb = item % nkb;
-    const _Float16* ks = lds_h + (item / nkb) * head_lds;     // [tpad][40]
-    const _Float16* vt = ks + (size_t)tpad * 40;             // [32][tpad + 4]
-    const int q0 = qb * 32;
-    half8 qf[2];
+  const int n_items = NH * nkb;
+  // the item's queries (B operand, straight from HBM) are fetched one item ahead: qn is issued before
+  // the current item's products and softmax, so its latency is not on the wave's path
+  auto load_q = [&](int hh, int qb, half8 (&q)[2]) __attribute__((always_inline)) {
+    const int qrow = qb * 32 + c;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qf[s][e] = (_Float16)0.f;
-      if (q0 + c < n)
-        qf[s] = *(const half8*)(qkv + toff(r0 + q0 + c, head * HEAD_DIM + 16 * s + 8 * h, 3 * HID / 16));
+      for (int e = 0; e < 8; ++e) q[s][e] = (_Float16)0.f;
+      if (hh < NH && qrow < n)
+        q[s] = *(const half8*)(qkv + toff(r0 + qrow, (head0 + hh) * HEAD_DIM + 16 * s + 8 * h, 3 * HID / 16));
     }
+  };
+  // items (head of the pair, query block) = hh * nkb + qb, dealt round-robin to the four waves; the pair is
+  // stepped without a division
+  auto advance = [&](int& hh, int& qb) __attribute__((always_inline)) {
+    qb += 4;
+    while (qb >= nkb && hh < NH) {
+      qb -= nkb;
+      ++hh;
+    }
+  };
+  int hh_cur = 0, qb_cur = wave - 4;
+  advance(hh_cur, qb_cur);
+  half8 qf[2], qn[2];
+  load_q(hh_cur, qb_cur, qf);
+  {
+    // Staging: thread = (16-byte part of a row, row mod 64).  ALL of a thread's global loads are issued
+    // before the first LDS write (one row per loop trip, load -> wait -> write, paid the HBM latency up to
+    // eight times in a row).
+    constexpr int RI = KB / 2;   // rows rl + 64 i, i < RI, cover the TP rows
+    const int part = tid & 3, rl = tid >> 2;
+    half8 kreg[NH][RI], vreg[NH][RI];
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+      for (int i = 0; i < RI; ++i) {
+        const int row = rl + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kreg[hh][i][e] = (_Float16)0.f; vreg[hh][i][e] = (_Float16)0.f; }
+        if (row < n) {
+          kreg[hh][i] = *(const half8*)(qkv + toff(r0 + row, HID + (head0 + hh) * HEAD_DIM + part * 8, 3 * HID / 16));
+          vreg[hh][i] = *(const half8*)(qkv + toff(r0 + row, 2 * HID + (head0 + hh) * HEAD_DIM + part * 8, 3 * HID / 16));
+        }
+      }
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+      for (int i = 0; i < RI; ++i) {
+        const int row = rl + 64 * i;
+        _Float16* ks_w = lds_h + hh * head_lds;
+        _Float16* vt_w = ks_w + (size_t)TP * 40;
+        *(half8*)(ks_w + row * 40 + part * 8) = kreg[hh][i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vt_w[(part * 8 + e) * vstride + row] = vreg[hh][i][e];
+      }
+  }
+  __syncthreads();
+  if (dbg) ts_stage = __builtin_amdgcn_s_memtime();
+  const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
+  while (hh_cur < NH) {
+    uint64_t ta = 0, tb = 0;
+    if (dbg) ta = __builtin_amdgcn_s_memtime();
+    const int head = head0 + hh_cur;
+    const int qb = qb_cur;
+    const _Float16* ks = lds_h + hh_cur * head_lds;           // [TP][40]
+    const _Float16* vt = ks + (size_t)TP * 40;               // [32][TP + 4]
+    const int q0 = qb * 32;
+    int hh_nxt = hh_cur, qb_nxt = qb_cur;
+    advance(hh_nxt, qb_nxt);
+    load_q(hh_nxt, qb_nxt, qn);
     f32x16 sc[KB];
+    // S^T = K Q^T for EVERY key block of the instantiation, back to back (rows beyond the sequence are zero in
+    // LDS): no branch between the LDS reads and the products, so the reads are issued ahead and the products
+    // pipeline.  (Per block behind `kb < nkb` branches, with the running maximum inside, each block was a
+    // serial chain read -> 2 MFMAs -> drain -> 8 v_max3 of ~430 cycles: stamps.)  Raw scores stay in the
+    // accumulator; the 1/sqrt(32) scale is folded into the exponent below.
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const half8 a0 = *(const half8*)(ks + (kb * 32 + c) * 40 + 8 * h);
+      const half8 a1 = *(const half8*)(ks + (kb * 32 + c) * 40 + 16 + 8 * h);
+      sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[0], z, 0, 0, 0);
+      sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[1], sc[kb], 0, 0, 0);
+    }
+    // att_max3 is inline asm, which hipcc's hazard recognizer does not see reading the MFMA result: the wait
+    // states an XDL write needs before a VALU read (11 for the 8-pass 32x32x16) are supplied by hand -- ONE
+    // block of nops that takes every accumulator as an in/out operand, so that it cannot be scheduled above
+    // any of the products.
+    if constexpr (KB == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]));
+    else if constexpr (KB == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
+    else if constexpr (KB == 6)
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]));
+    else
+      asm volatile("s_nop 7\n\ts_nop 7"
+                   : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]), "+v"(sc[6]), "+v"(sc[7]));
+    // key >= n -> -inf: only in the block(s) that hold padding, behind a wave-uniform branch (the empty asm
+    // keeps the compiler from turning the branch into 16 selects per block of EVERY item)
+    int lim = n - 4 * h;                 // the lane's keys 32 kb + 8 (i >> 2) + (i & 3) >= lim are padding
+    asm volatile("" : "+v"(lim));        // opaque per item: as a loop invariant the 16 x KB compares were hoisted
+                                         // into 128 live lane masks (and spilled)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if ((kb + 1) * 32 > n) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kb * 32 + (i & 3) + 8 * (i >> 2) >= lim) sc[kb][i] = -INFINITY;
+      }
+    }
+    // running maximum by v_max3_f32 (two new elements per instruction) over the blocks the sequence has
     float m = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       if (kb < nkb) {
-        f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const half8 a = *(const half8*)(ks + (kb * 32 + c) * 40 + 16 * s + 8 * h);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], acc, 0, 0, 0);
-        }
-        // raw scores stay in the accumulator; only the sequence's ragged LAST key block
-        // needs the key < n mask (wave-uniform branch), and the 1/sqrt(32) scale is folded
-        // into the exponent below: the softmax is VALU-bound, every op per element counts
-        if (kb == nkb - 1 && (n & 31) != 0) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h >= n) acc[i] = -INFINITY;
-        }
-        // running maximum by v_max3_f32 (two new elements per instruction).  att_max3 is inline
-        // asm, which hipcc's hazard recognizer does not see reading the MFMA result: the wait
-        // states an XDL write needs before a VALU read (11 for the 8-pass 32x32x16) are supplied
-        // by hand, as nops that take the accumulator as an in/out operand.
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) m = att_max3(m, acc[i], acc[i + 1]);
-        sc[kb] = acc;
+        for (int i = 0; i < 16; i += 2) m = att_max3(m, sc[kb][i], sc[kb][i + 1]);
       }
     }
     m = fmaxf(m, __shfl_xor(m, 32));
+    if (dbg) {
+      asm volatile("" : "+v"(m));
+      tb = __builtin_amdgcn_s_memtime();
+      t_qk += tb - ta;
+      ta = tb;
+    }
     f32x2 l2 = {0.f, 0.f};
     const float c2 = scale * 1.4426950408889634f;   // exp(scale * (s - m)) = exp2(c2 * s - c2 * m)
     const float mc = m * c2;
@@ -1189,6 +1322,12 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
     }
     float l = l2[0] + l2[1];
     l += __shfl_xor(l, 32);
+    if (dbg) {
+      asm volatile("" : "+v"(l));
+      tb = __builtin_amdgcn_s_memtime();
+      t_exp += tb - ta;
+      ta = tb;
+    }
     f32x16 o;
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
@@ -1210,6 +1349,12 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
         }
       }
     }
+    if (dbg) {
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o));
+      tb = __builtin_amdgcn_s_memtime();
+      t_pv += tb - ta;
+      ta = tb;
+    }
     if (q0 + c < n) {
       const float inv = 1.f / l;
 #pragma unroll
@@ -1219,6 +1364,24 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
         for (int j = 0; j < 4; ++j) t[j] = (_Float16)(o[4 * g + j] * inv);
         *(half4*)(ctx + toff(r0 + q0 + c, head * HEAD_DIM + 8 * g + 4 * h, HID / 16)) = t;
       }
+    }
+    qf[0] = qn[0];
+    qf[1] = qn[1];
+    hh_cur = hh_nxt;
+    qb_cur = qb_nxt;
+    if (dbg) t_out += __builtin_amdgcn_s_memtime() - ta;
+  }
+  if (dbg && lane == 0) {
+    float* d = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    if ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) < 1024) {   // the buffer holds 4096 waves x 8 floats
+      d[0] = (float)(__builtin_amdgcn_s_memtime() - ts_entry);   // cycles, whole wave
+      d[1] = (float)(ts_stage - ts_entry);                       // staging + barrier
+      d[2] = (float)t_qk;
+      d[3] = (float)t_exp;
+      d[4] = (float)t_pv;
+      d[5] = (float)t_out;
+      d[6] = (float)n_items;
+      d[7] = (float)n;
     }
   }
 }
@@ -1391,21 +1554,38 @@ static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Floa
     return;
   }
   if (K == 384 && EPI != EPI_BIAS_RES_LN && rf_knob_linear_dma && tokens >= 8192) {
-    const size_t lds = (size_t)LD_SLOTS * LD_FRAGS * RF_FRAG_BYTES + RF_FRAG_BYTES + (size_t)N * 2;
+    const size_t lds = (size_t)LD_SLOTS * LD_FRAGS * RF_FRAG_BYTES + RF_FRAG_BYTES + (size_t)N * 4;   // ring + dump + fp32 bias
     constexpr int E = (EPI == EPI_BIAS_GELU ? EPI_BIAS_GELU : EPI_BIAS);
     // 256-token workgroups once they still fill the chip (>= 256 of them would need 64 k tokens;
     // from ~48 k the halved weight traffic and per-wave overhead outweigh the idle CUs)
     const bool wide = rf_knob_linear_dma == 2 || (rf_knob_linear_dma == 1 && tokens >= 49152);   // 3: never
-    static rf_lds_attr attr[2];   // per epilogue (template), per form, per device
-    if (wide) (void)rf_ensure_lds(attr[1], (const void*)k_linear_dma<E, 1>, lds);
-    else (void)rf_ensure_lds(attr[0], (const void*)k_linear_dma<E, 0>, lds);
     float* dbgp = (rf_knob_debug_epi == (int)EPI) ? (float*)rf_debug_buffer : nullptr;
-    if (wide)
-      hipLaunchKernelGGL((k_linear_dma<E, 1>), dim3((tokens + 2 * LD_TOK - 1) / (2 * LD_TOK)), dim3(LD_WAVES * 64), lds,
-                         st, X, Wt, bias, out, N, m_ptr, dbgp, rf_knob_linear_dbg);
-    else
-      hipLaunchKernelGGL((k_linear_dma<E, 0>), dim3((tokens + LD_TOK - 1) / LD_TOK), dim3(LD_WAVES * 64), lds, st, X,
-                         Wt, bias, out, N, m_ptr, dbgp, rf_knob_linear_dbg);
+    const dim3 grid_w((tokens + 2 * LD_TOK - 1) / (2 * LD_TOK)), grid_n((tokens + LD_TOK - 1) / LD_TOK), block(LD_WAVES * 64);
+#define RF_LD_LAUNCH(W, A)                                                                                     \
+  do {                                                                                                         \
+    static rf_lds_attr attr_;   /* per instantiation, per device */                                            \
+    (void)rf_ensure_lds(attr_, (const void*)k_linear_dma<E, W, A>, lds);                                       \
+    hipLaunchKernelGGL((k_linear_dma<E, W, A>), (W) ? grid_w : grid_n, block, lds, st, X, Wt, bias, out, N, m_ptr, dbgp); \
+  } while (0)
+#ifdef RF_EXPERIMENTS
+    if (wide && rf_knob_linear_dbg) {   // ablations of the wide form (results wrong)
+      switch (rf_knob_linear_dbg) {
+        case 1: RF_LD_LAUNCH(1, 1); return;
+        case 2: RF_LD_LAUNCH(1, 2); return;
+        case 4: RF_LD_LAUNCH(1, 4); return;
+        case 8: RF_LD_LAUNCH(1, 8); return;
+        case 12: RF_LD_LAUNCH(1, 12); return;
+        case 16: RF_LD_LAUNCH(1, 16); return;
+        case 32: RF_LD_LAUNCH(1, 32); return;
+        case 48: RF_LD_LAUNCH(1, 48); return;
+        case 50: RF_LD_LAUNCH(1, 50); return;
+        default: break;
+      }
+    }
+#endif
+    if (wide) RF_LD_LAUNCH(1, 0);
+    else RF_LD_LAUNCH(0, 0);
+#undef RF_LD_LAUNCH
     return;
   }
   if (K == 384 && rf_knob_k384_ntb == 4 && tokens >= 8192)   // 128-token tiles
@@ -1532,14 +1712,32 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
   const size_t attn_lds = (size_t)T * 2 * HEAD_DIM * 2;
   static rf_lds_attr attn_attr;
   if (T > 32 * ATT_MAX_KB) RF_HIP(rf_ensure_lds(attn_attr, (const void*)k_attention, attn_lds));
-  const int tpad_max = (T + 31) / 32 * 32;
-  const size_t mfma_lds = ATT_HEADS * ((size_t)tpad_max * 80 + (size_t)32 * (tpad_max + 4) * 2);  // 74 KB at T = 256
-  // instantiation by the batch's width: <key blocks, minimum waves per SIMD the register budget must allow>
+  // instantiation by the batch's width: <key blocks, minimum waves per SIMD the register budget must allow, heads
+  // per workgroup>
   const int att_kb = T <= 64 ? 2 : (T <= 128 ? 4 : (T <= 192 ? 6 : 8));
-  const void* att_fn = att_kb == 2 ? (const void*)k_attention_mfma<2, 4> : att_kb == 4 ? (const void*)k_attention_mfma<4, 3>
-                     : att_kb == 6 ? (const void*)k_attention_mfma<6, 2> : (const void*)k_attention_mfma<8, 2>;
-  static rf_lds_attr mfma_attrs[4];
-  if (T <= 32 * ATT_MAX_KB) RF_HIP(rf_ensure_lds(mfma_attrs[att_kb / 2 - 1], att_fn, mfma_lds));
+  const int att_nh = rf_knob_att_heads;
+  const size_t att_tp = (size_t)att_kb * 32;   // the kernel's LDS image has the instantiation's shape
+  const size_t mfma_lds = att_nh * (att_tp * 80 + (size_t)32 * (att_tp + 4) * 2);  // 37 KB per head at T = 256
+  static rf_lds_attr mfma_attrs[8];
+#define RF_ATT_CASE(KB_, W2, W1)                                                                                  \
+  case KB_:                                                                                                      \
+    if (att_nh == 2) {                                                                                           \
+      RF_HIP(rf_ensure_lds(mfma_attrs[KB_ - 2], (const void*)k_attention_mfma<KB_, W2, 2>, mfma_lds));           \
+    } else {                                                                                                     \
+      RF_HIP(rf_ensure_lds(mfma_attrs[KB_ - 1], (const void*)k_attention_mfma<KB_, W1, 1>, mfma_lds));           \
+    }                                                                                                            \
+    break;
+  if (T <= 32 * ATT_MAX_KB) {
+    switch (att_kb) {
+      RF_ATT_CASE(2, 4, 6)
+      RF_ATT_CASE(4, 3, 4)
+      RF_ATT_CASE(6, 2, 3)
+      RF_ATT_CASE(8, 2, 3)
+      default: break;
+    }
+  }
+#undef RF_ATT_CASE
+  float* const att_dbg = (rf_knob_debug_epi == 2) ? (float*)rf_debug_buffer : nullptr;   // clock stamps (experiments build)
   _Float16* x = ws.x;
   _Float16* y = ws.y;
   for (int l = 0; l < L; ++l) {
@@ -1550,11 +1748,22 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
     launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
                             3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
     if (T <= 32 * ATT_MAX_KB) {
-      const dim3 ag(B, c.heads / ATT_HEADS);
-      if (att_kb == 2) hipLaunchKernelGGL((k_attention_mfma<2, 4>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx);
-      else if (att_kb == 4) hipLaunchKernelGGL((k_attention_mfma<4, 3>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx);
-      else if (att_kb == 6) hipLaunchKernelGGL((k_attention_mfma<6, 2>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx);
-      else hipLaunchKernelGGL((k_attention_mfma<8, 2>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx);
+      const dim3 ag(B, c.heads / att_nh);
+#define RF_ATT_CASE(KB_, W2, W1)                                                                                          \
+  case KB_:                                                                                                              \
+    if (att_nh == 2)                                                                                                     \
+      hipLaunchKernelGGL((k_attention_mfma<KB_, W2, 2>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx, att_dbg); \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((k_attention_mfma<KB_, W1, 1>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx, att_dbg); \
+    break;
+      switch (att_kb) {
+        RF_ATT_CASE(2, 4, 6)
+        RF_ATT_CASE(4, 3, 4)
+        RF_ATT_CASE(6, 2, 3)
+        RF_ATT_CASE(8, 2, 3)
+        default: break;
+      }
+#undef RF_ATT_CASE
     }
     else
       hipLaunchKernelGGL(k_attention, dim3(B, c.heads), dim3(256), attn_lds, st, ws.qkv, ws.tok_off,

@@ -62,7 +62,8 @@ RF_KNOB(rf_knob_ffn2_ntb, 4)           // encoder: the same for the K = 1536 Lay
 RF_KNOB(rf_knob_gemm_tile, 3)          // encoder: GEMMs on k_gemm_tile (both operands through the LDS-DMA ring): 1 FFN2, 2 out-proj, 4 QKV, 8 FFN1
 RF_KNOB(rf_knob_encode_graph, 1)       // encoder: query-sized forwards replay a cached hipGraph
 RF_KNOB(rf_knob_linear_dbg, 0)         // encoder: k_linear_dma ablation bits (results wrong)
-RF_KNOB(rf_knob_debug_epi, 1)          // encoder: which k_linear_dma epilogue writes clock stamps
+RF_KNOB(rf_knob_debug_epi, 1)          // encoder: which kernel writes clock stamps (0 QKV, 1 FFN1, 2 attention)
+RF_KNOB(rf_knob_att_heads, 1)          // encoder: heads per attention workgroup (1 | 2)
 #undef RF_KNOB
 #ifdef RF_EXPERIMENTS
 extern int rf_tuning_generation;   // bumped by rf_set_tuning: cached encode graphs of older settings are not replayed

@@ -274,7 +274,7 @@ def test_config5_shard_size_768_properties(gpu_device):
 
 
 @pytest.mark.parametrize("n,b,k", [(40_000, 256, 10), (25_000, 300, 10), (3_000, 100, 10), (70_000, 65, 64),
-                                   (8_193, 129, 5)])
+                                   (8_193, 129, 5), (20_000, 200, 10)])   # 20 000 rows: an ODD number of 32-row blocks
 def test_wide_sweep_parity(gpu_device, n, b, k):
     """Batches above 64 queries at dim 384 take the wide sweep (scan_wide.hip: up to
     256 queries per corpus pass); same oracle, same bit-exact bar."""

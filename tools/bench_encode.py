@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--tune", default="", help="rf_set_tuning pairs, e.g. ffn2_ntb=4,linear_dma=0")
     ap.add_argument("--texts", action="store_true", help="also time the text -> tokenizer -> encoder path")
     ap.add_argument("--stamps", action="store_true", help="clock stamps of the last k_linear_dma launch")
-    ap.add_argument("--stamp-epi", type=int, default=1, help="0 = QKV, 1 = FFN1")
+    ap.add_argument("--stamp-epi", type=int, default=1, help="0 = QKV, 1 = FFN1, 2 = attention")
     ap.add_argument("--linear-dbg", type=int, default=0, help="ablation bits of k_linear_dma (results wrong)")
     args = ap.parse_args()
     import torch
@@ -77,6 +77,16 @@ def main():
         emb.encode_ids(ids, ln)
         torch.cuda.synchronize()
         lib.rf_debug_set_buffer(None)
+        if args.stamp_epi == 2:     # attention: [workgroup][wave] x {cycles, staging, QK + max, exp, PV, output, items, tokens}
+            st = buf.view(1024, 4, 8).cpu().numpy()
+            ok = st[..., 0] > 0
+            tot, stage, qk, ex, pv, outp, items, ntok = (st[..., i][ok] for i in range(8))
+            per = np.maximum(items / 4.0, 1.0)
+            print("attention stamps (last launch, %d waves, median tokens %d, items/workgroup %d): wave %.0f cycles = staging %.0f + "
+                  "per item (x%.1f): QK+max %.0f, exp+sum %.0f, PV %.0f, scale+store %.0f" %
+                  (ok.sum(), np.median(ntok), np.median(items), np.median(tot), np.median(stage), np.median(per),
+                   np.median(qk / per), np.median(ex / per), np.median(pv / per), np.median(outp / per)))
+            return
         st = buf.view(512, 8, 8).cpu().numpy()
         ok = st[..., 1] > 0
         cyc, ticks, pre, wait, nph = (st[..., i][ok] for i in range(5))

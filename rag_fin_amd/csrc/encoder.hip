@@ -1355,6 +1355,10 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
       t_pv += tb - ta;
       ta = tb;
     }
+    // the next item's queries are consumed HERE, ahead of the output stores: the wait the compiler puts in
+    // front of their first use then covers the two loads only (issued ~4 000 cycles ago) -- behind the
+    // conditional stores it is a vmcnt(0) that also waits for the stores (+2 % on the whole encoder)
+    asm volatile("" : "+v"(qn[0]), "+v"(qn[1]));
     if (q0 + c < n) {
       const float inv = 1.f / l;
 #pragma unroll

@@ -166,6 +166,37 @@ def test_all_gemm_paths_agree_and_match_the_oracle(gpu_device):
     assert np.abs(one - want1).max() < TOL   # a single 12-token query (the reference's serving mode)
 
 
+@pytest.mark.parametrize("B,T", [(40, 256), (200, 256), (96, 100), (1200, 7)])
+def test_large_batch_edge_lengths_at_any_offset_match_the_oracle(gpu_device, B, T):
+    """Batches of >= 8192 token slots (weights through the LDS-DMA ring, packed tokens): probe sequences
+    of edge lengths (1, 31, 32, 33, ..., T) sit between random fillers, so their first token falls on
+    arbitrary offsets inside the 32-token tiles of the packed stream and the last one ends it inside a
+    tile; each probe is compared with the numpy oracle (2 layers).  (Written for an attention kernel on
+    global 32-token key blocks -- measured slower and dropped, DESIGN.md 4.5 -- and kept: the tiled
+    activations and the ragged-block masks are exercised at every offset.)"""
+    from rag_fin_amd.embedder import Embedder
+    cfg = dict(oenc.MINILM_L6, layers=2, vocab_size=3000)
+    w = oenc.random_weights(cfg, 17)
+    emb = Embedder(w, cfg, device=gpu_device)
+    rng = np.random.default_rng(B + T)
+    assert B * T >= 8192
+    lens = rng.integers(1, T + 1, B).astype(np.int32)
+    edge = [l for l in (T, 1, 31, 32, 33, 64, 65, T - 1, T // 2) if 1 <= l <= T]
+    probes = list(range(0, B, max(B // len(edge), 1)))[:len(edge)]
+    for p_, l in zip(probes, edge):
+        lens[p_] = l
+    lens[B - 1] = T            # the last sequence ends the packed stream inside (or at the end of) a block
+    probes = sorted(set(probes + [B - 1, B - 2]))
+    ids = rng.integers(1, 3000, (B, T)).astype(np.int32)
+    got = emb.encode_ids(ids, lens, out_dtype="float32").cpu().numpy()
+    want = oenc.encode(oenc.round_weights_fp16(w), cfg, ids[probes], lens[probes])
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    assert len({int(starts[p_]) % 32 for p_ in probes}) >= min(4, len(probes) // 2)   # misaligned starts are covered
+    err = np.abs(got[probes] - want).max(axis=1)
+    assert err.max() < TOL, (err, lens[probes], starts[probes] % 32)
+    assert np.isfinite(got).all()
+
+
 def test_large_batch_forward_repeats_bitwise(gpu_device):
     """Short soak of the LDS-DMA GEMMs (k_linear_dma waits on hand-counted vmcnt / lgkmcnt values;
     a misplaced count gives a RARE wrong tile): 40 forwards of a 66 k-slot batch on fresh ids,

@@ -613,8 +613,6 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-pa
   }
   __syncthreads();   // bias in LDS (this barrier also drains the first DMA pieces: needed at once anyway)
 
-  // lane's slot in the tiled output: token block (t0/32 + tb), feature 4 h, lane c (see toff())
-  _Float16* const out_lane = out + (((ABL & 8) ? (size_t)tb : ((size_t)(t0 >> 5) + tb)) * (size_t)(N / 16) * 64 + c) * 8 + 4 * h;
   // lane's 16 features of a block: 8 g + 4 h + j -> four 16-byte reads of the fp32 bias
   const uint32_t bias_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)bias_l + (uint32_t)h * 16u;
   typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -631,10 +629,15 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-pa
   auto bias_landed = [&](Bias& bq) __attribute__((always_inline)) {   // call after a wait that covers the four reads
     asm volatile("" : "+v"(bq.q[0]), "+v"(bq.q[1]), "+v"(bq.q[2]), "+v"(bq.q[3]));
   };
-  // epilogue of one finished block: acc[4 g + j] = Y[token][32 blk + 8 g + 4 h + j], in four quads
-  // (quad g = one 8-byte store).  Four values = four independent dependency chains: a dependent
-  // v_fma_f32 issues every ~8 cycles, four interleaved chains every ~5.3 (tools/ubench/mfma_valu2.hip).
-  auto epi_quad = [&](const f32x16& acc, const Bias& bq, uint32_t blk, int g) __attribute__((always_inline)) {
+  // epilogue of one finished block: acc[4 g + j] = Y[token][32 blk + 8 g + 4 h + j], in four quads.  Four
+  // values = four independent dependency chains: a dependent v_fma_f32 issues every ~8 cycles, four
+  // interleaved chains every ~5.3 (tools/ubench/mfma_valu2.hip).  Stores are 16 bytes per lane: the 16-byte
+  // slot (token, 8 features) of the tiled layout is split between lanes c (h = 0) and c + 32 (h = 1), so the
+  // packed quads 2 m and 2 m + 1 go through v_permlane32_swap (cdna_hip_programming.md T21) and the wave's
+  // 64 lanes then hold fragment 2 blk + m whole, lane-linear -- two global_store_dwordx4 per block instead of
+  // four dwordx2 (the stores are issue-bound per instruction, not per byte).
+  _Float16* const out_lane_w = out + (((ABL & 8) ? (size_t)tb : ((size_t)(t0 >> 5) + tb)) * (size_t)(N / 16) * 64 + lane) * 8;
+  auto epi_quad = [&](const f32x16& acc, const Bias& bq, uint32_t blk, int g, uint2& even) __attribute__((always_inline)) {
     if (ABL & 4) return;
     float y[4];
 #pragma unroll
@@ -644,14 +647,21 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-pa
       for (int j = 0; j < 4; ++j) y[j] = gelu_erf_s(y[j]);
     }
     const half4 o = {(_Float16)y[0], (_Float16)y[1], (_Float16)y[2], (_Float16)y[3]};
+    const uint2 pk = __builtin_bit_cast(uint2, o);
+    if (!(g & 1)) {
+      even = pk;
+      return;
+    }
+    const auto sx = __builtin_amdgcn_permlane32_swap(even.x, pk.x, false, false);
+    const auto sy = __builtin_amdgcn_permlane32_swap(even.y, pk.y, false, false);
     // unconditional: rows >= M of the last tile exist (the workspace is padded to whole tiles) and
-    // nobody reads them -- and a fixed 4 stores per block keeps the vmcnt arithmetic exact.
-    // toff(token, 32 blk + 8 g + 4 h) = per-lane base + a wave-uniform offset:
-    *(half4*)(out_lane + ((size_t)((ABL & 8) ? (blk & 1u) : blk) * 2 + (g >> 1)) * 512 + (g & 1) * 256) = o;
+    // nobody reads them -- and a fixed 2 stores per block keeps the vmcnt arithmetic exact.
+    *(uint4*)(out_lane_w + ((size_t)((ABL & 8) ? (blk & 1u) : blk) * 2 + (g >> 1)) * 512) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
   };
   auto epilogue = [&](const f32x16& acc, const Bias& bq, uint32_t blk) __attribute__((always_inline)) {
+    uint2 even;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) epi_quad(acc, bq, blk, g);
+    for (int g = 0; g < 4; ++g) epi_quad(acc, bq, blk, g, even);
   };
   // matrix part of a phase: this wave's feature block (par) of the slot x its 32 tokens.  In the WIDE
   // form the epilogue of the PREVIOUS block (prev, blk_prev) is cut into the same instruction stream:
@@ -665,6 +675,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-pa
     rf_u32x4 fa[2][WL_GRP];
     constexpr int NG = KS / WL_GRP;   // 6
     Bias bq;
+    uint2 even;                           // the even quad's packed outputs, waiting for their odd partner
     if (prev) bias_issue(bq, blk_prev);   // older than every fragment read of this part: covered by its first wait
     if (!(ABL & 16)) lds_read_group<0>(fa[0], sa);
 #pragma unroll
@@ -692,7 +703,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-pa
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), acc, 0, 0, 0);
       }
       if (prev && kk % 6 == 5) {
-        epi_quad(*prev, bq, blk_prev, kk / 6);
+        epi_quad(*prev, bq, blk_prev, kk / 6, even);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -702,14 +713,14 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-pa
     // Block b's epilogue runs under block b + 1's MFMAs.  Before the loop there is no finished block:
     // the first part "finishes" an all-zero accumulator into block 0's place, which the real block 0
     // (stored later by the same lanes) overwrites -- no branch in the loop, and the VMEM count per
-    // phase (6 pieces + 8 stores) stays what the counted wait below assumes.
+    // phase (6 pieces + 4 stores) stays what the counted wait below assumes.
     f32x16 acc0, acc1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (uint32_t ph = 0; ph < n_ph; ++ph) {
       uint64_t ts0 = 0;
       if (dbg) ts0 = __builtin_amdgcn_s_memtime();
       // the previous phase issued, after the barrier that follows my pieces of phase ph, exactly 6
-      // pieces (phase ph+1) and 8 stores: those may stay in flight, everything older has landed
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + 8) : "memory");
+      // pieces (phase ph+1) and 4 stores: those may stay in flight, everything older has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + 4) : "memory");
       __builtin_amdgcn_s_barrier();
       if (dbg) t_wait += __builtin_amdgcn_s_memtime() - ts0;
       const Pieces nxt = pieces_of(ph + 2);
@@ -728,7 +739,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-pa
     for (uint32_t ph = 0; ph < n_ph; ++ph) {
       uint64_t ts0 = 0;
       if (dbg) ts0 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + 4) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_PW + 2) : "memory");
       __builtin_amdgcn_s_barrier();
       if (dbg) t_wait += __builtin_amdgcn_s_memtime() - ts0;
       const Pieces nxt = pieces_of(ph + 2);
@@ -745,7 +756,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-pa
       epilogue(acc, bq, 2u * ph + (uint32_t)par);
     }
   }
-  if (ABL & 4) asm volatile("" ::"v"(out_lane));
+  if (ABL & 4) asm volatile("" ::"v"(out_lane_w));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump pieces must land before the LDS is handed on
   if (dbg && lane == 0) {
     float* o = dbg + ((size_t)blockIdx.x * LD_WAVES + wave) * 8;
@@ -778,12 +789,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GT_TOK 128
 #define GT_SLOTS 4
 #define GT_STAGE_FRAGS 32                  // 1-KiB fragments per stage: 4 x 2 (activations) + 12 x 2 (weights)
-template <int EPI, int KS>                 // KS = K / 16 (24 | 96)
+template <int EPI, int KS, int DMODE>      // KS = K / 16 (24 | 96); DMODE: who issues the LDS-DMA pieces (below)
 __global__ void __launch_bounds__(512, 1) k_gemm_tile(
     const _Float16* __restrict__ X, const uint4* __restrict__ Wt, const _Float16* __restrict__ bias,
     _Float16* __restrict__ out, int ldo, const int32_t* __restrict__ m_ptr, const _Float16* __restrict__ res,
-    const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta, float eps) {
+    const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta, float eps, float* __restrict__ dbg) {
   constexpr int NST = KS / 2;              // stages (k-steps of 32)
+  // diagnostic run only (dbg != nullptr, tools/bench_encode.py --stamps --stamp-epi 3 | 4): clock stamps per wave
+  const uint64_t ts_entry = dbg ? __builtin_amdgcn_s_memtime() : 0;
+  uint64_t ts_loop = 0, ts_epi = 0, t_wait = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   rf_u32x4* slots = (rf_u32x4*)smem_raw;                           // [GT_SLOTS][32 frags][64 lanes]
   rf_u32x4* const dump = slots + GT_SLOTS * GT_STAGE_FRAGS * 64;   // 1 KiB: pieces issued past the last stage
@@ -804,21 +818,29 @@ __global__ void __launch_bounds__(512, 1) k_gemm_tile(
   // (w' = wave & 3): p < 8: activation block p >> 1, fragment p & 1; p >= 8: weight block (p - 8) >> 1.
   // A wave's outstanding pieces at the wait in front of stage t are then either {t, t + 2} (its half
   // brought t) or {t + 1}: `vmcnt(8)` is right for both.
+  // DMODE 1: EVERY wave brings 4 pieces of every stage, one after each sixth MFMA of the stage before
+  // (mfma_stage): 8 pieces in a burst ahead of the MFMAs cost the issuing wave ~1 200 cycles, during which the
+  // stage's barrier holds everybody else -- spread, the stalls of a piece sit on top of six queued MFMAs.
   const int half = wave >> 2;
-  const int p0 = (wave & 3) * 8;
-  const uint4* src0;   // lane's address of fragment kk = 0 of my first block
-  if (p0 < 8) src0 = (const uint4*)X + ((size_t)(t0 >> 5) * KS) * 64 + lane;
-  else src0 = Wt + ((size_t)((n0 >> 5) + ((p0 - 8) >> 1)) * KS) * 64 + lane;
-  auto issue_stage = [&](int s) {   // the issuing half brings all 32 pieces, live or not (uniform vmcnt arithmetic)
-    if (((s + 1) & 1) != half) return;
+  constexpr int NP = DMODE == 1 ? 4 : 8;    // pieces per wave per issue
+  const int p0 = DMODE == 1 ? wave * 4 : (wave & 3) * 8;
+  // a piece's source = a wave-uniform base (scalar registers) + the lane's 16 bytes: nothing of it lives in
+  // vector registers across the MFMAs it is issued between
+  const char* const my_base = (p0 < 8) ? (const char*)X + ((size_t)((t0 >> 5) + (p0 >> 1)) * KS) * 1024
+                                       : (const char*)Wt + ((size_t)((n0 >> 5) + ((p0 - 8) >> 1)) * KS) * 1024;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  auto issue_piece = [&](int s, int j) __attribute__((always_inline)) {   // j = 2 b + f: block b of mine, fragment f
     const bool live = s < NST;
-    const uint4* sp = src0 + (size_t)(live ? 2 * s : 0) * 64;
-    rf_u32x4* dp = live ? slots + ((s % GT_SLOTS) * GT_STAGE_FRAGS + p0) * 64 : dump;
-    const int dstep = live ? 64 : 0;
+    const char* src = my_base + ((size_t)(j >> 1) * KS + (size_t)(live ? 2 * s : 0) + (j & 1)) * 1024;
+    rf_u32x4* dst = live ? slots + ((s % GT_SLOTS) * GT_STAGE_FRAGS + p0 + j) * 64 : dump;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane_off),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto issue_stage = [&](int s) __attribute__((always_inline)) {   // all of my pieces of stage s, live or not (uniform vmcnt arithmetic)
+    if (DMODE == 2 && s >= 3) return;   // ablation (experiments build; results wrong): no LDS-DMA in the stage loop
+    if (DMODE != 1 && ((s + 1) & 1) != half) return;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)   // j = 2 b + f: block b of my four, fragment f
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp + (size_t)(j >> 1) * (KS * 64) + (j & 1) * 64),
-                                       (__attribute__((address_space(3))) void*)(dp + j * dstep), 16, 0, 0);
+    for (int j = 0; j < NP; ++j) issue_piece(s, j);
   };
   issue_stage(0);
   issue_stage(1);
@@ -856,24 +878,39 @@ __global__ void __launch_bounds__(512, 1) k_gemm_tile(
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(wf[4]) : "v"(sb + wa));
     asm volatile("ds_read_b128 %0, %1 offset:4352" : "=v"(wf[5]) : "v"(sb + wa));
   };
-  auto mfma_stage = [&](rf_u32x4 (&xb)[4], rf_u32x4 (&wf)[6]) __attribute__((always_inline)) {
-    __builtin_amdgcn_s_setprio(1);
+  // nxt (DMODE 1): the stage whose pieces this wave issues between the MFMAs
+  auto mfma_stage = [&](rf_u32x4 (&xb)[4], rf_u32x4 (&wf)[6], int nxt) __attribute__((always_inline)) {
+    if (DMODE != 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ft = 0; ft < 6; ++ft)
+    for (int ft = 0; ft < 6; ++ft) {
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
         acc[ft][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wf[ft]), __builtin_bit_cast(half8, xb[tt]),
                                                              acc[ft][tt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+      if (DMODE == 1 && ft >= 1 && ft <= 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(nxt, ft - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (DMODE != 1) __builtin_amdgcn_s_setprio(0);
   };
   auto sync_stage = [&]() __attribute__((always_inline)) {
+    uint64_t ts0 = 0;
+    if (dbg) ts0 = __builtin_amdgcn_s_memtime();
     // my pieces of the stage have landed (those of the next two stages may stay in flight) ...
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     // ... after the barrier everybody's have, and everybody has READ the previous stage (its slot is free)
     __builtin_amdgcn_s_barrier();
+    if (dbg) t_wait += __builtin_amdgcn_s_memtime() - ts0;
   };
   rf_u32x4 xb0[4], wf0[6], xb1[4], wf1[6];
   static_assert(NST % 2 == 0, "stages are processed in pairs");
+  if (dbg) ts_loop = __builtin_amdgcn_s_memtime();
+  // vmcnt arithmetic of DMODE 1: the pieces of stage t + 3 go out under the MFMAs of stage t - 1, i.e. after the
+  // barrier of stage t (the slot they overwrite, that of stage t - 1, has been read by everybody by then); at
+  // the wait in front of stage t a wave has therefore issued, after its pieces of stage t, those of t + 1 and
+  // t + 2 (4 each): vmcnt(8), the same constant as in the other mode.
   sync_stage();
   read_stage(0, xb0, wf0);
   issue_stage(3);
@@ -884,25 +921,44 @@ __global__ void __launch_bounds__(512, 1) k_gemm_tile(
                  "+v"(wf0[2]), "+v"(wf0[3]), "+v"(wf0[4]), "+v"(wf0[5]));
     sync_stage();
     read_stage(s, xb1, wf1);
-    issue_stage(s + 3);
-    mfma_stage(xb0, wf0);
+    if (DMODE != 1) issue_stage(s + 3);
+    mfma_stage(xb0, wf0, s + 3);          // (DMODE 1) under the MFMAs of stage s-1: the pieces of stage s+3
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb1[0]), "+v"(xb1[1]), "+v"(xb1[2]), "+v"(xb1[3]), "+v"(wf1[0]), "+v"(wf1[1]),
                  "+v"(wf1[2]), "+v"(wf1[3]), "+v"(wf1[4]), "+v"(wf1[5]));
     if (s + 1 < NST) {   // even stage s+1: read into set 0, compute stage s from set 1
       sync_stage();
       read_stage(s + 1, xb0, wf0);
-      issue_stage(s + 4);
+      if (DMODE != 1) issue_stage(s + 4);
     }
-    mfma_stage(xb1, wf1);
+    mfma_stage(xb1, wf1, s + 4);          // (in the last trip: pieces past the last stage, into the dump slot)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump pieces must land before the LDS is handed on
+  if (dbg) ts_epi = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue: acc[ft][tt][j] = Y[t0 + 64 wm + 16 tt + c16][n0 + 96 wn + 16 ft + 4 g + j] ----------------
   const int fbase = n0 + 96 * wn + 4 * g;
   float mu[4], rstd[4];
+  // every global load of the epilogue -- bias, residual, LayerNorm scale and shift -- is issued HERE, ahead of
+  // the first use: spread through the epilogue (the scale and shift behind the LayerNorm's barriers) they were
+  // three to four memory round trips in a row, most of the epilogue's 15-17 k cycles (stamps)
+  half4 bvs[6], gvs[6], bes[6];
+  uint4 rrs[6][2];
 #pragma unroll
   for (int ft = 0; ft < 6; ++ft) {
-    const half4 bv = *(const half4*)(bias + fbase + 16 * ft);
+    bvs[ft] = *(const half4*)(bias + fbase + 16 * ft);
+    if (EPI == EPI_BIAS_RES_LN) {
+      gvs[ft] = *(const half4*)(gamma + fbase + 16 * ft);
+      bes[ft] = *(const half4*)(beta + fbase + 16 * ft);
+      // residual: ONE 16-byte lane-linear load per pair of token tiles (the fragment of token block
+      // 2 wm + tp, feature group 6 wn + ft, whole); the half exchange of the stores below, backwards, follows
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+        rrs[ft][tp] = *(const uint4*)(res + ((size_t)((t0 >> 5) + 2 * wm + tp) * (HID / 16) + (n0 >> 4) + 6 * wn + ft) * 512 + lane * 8);
+    }
+  }
+#pragma unroll
+  for (int ft = 0; ft < 6; ++ft) {
+    const half4 bv = bvs[ft];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
       if (EPI == EPI_BIAS_GELU) {
@@ -919,10 +975,20 @@ __global__ void __launch_bounds__(512, 1) k_gemm_tile(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[ft][tt][j] += (float)bv[j];
       }
-      if (EPI == EPI_BIAS_RES_LN) {
-        const half4 rv = *(const half4*)(res + toff(t0 + 64 * wm + 16 * tt + c16, fbase + 16 * ft, HID / 16));
+    }
+    if (EPI == EPI_BIAS_RES_LN) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[ft][tt][j] += (float)rv[j];
+      for (int tp = 0; tp < 2; ++tp) {
+        const uint4 r = rrs[ft][tp];
+        const auto sx = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
+        const uint2 lo = make_uint2(sx[0], sy[0]), hi = make_uint2(sx[1], sy[1]);
+        const half4 r0 = __builtin_bit_cast(half4, lo), r1 = __builtin_bit_cast(half4, hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[ft][2 * tp][j] += (float)r0[j];
+          acc[ft][2 * tp + 1][j] += (float)r1[j];
+        }
       }
     }
   }
@@ -955,24 +1021,49 @@ __global__ void __launch_bounds__(512, 1) k_gemm_tile(
       }
     }
   }
+  // Stores: 16 bytes per lane.  A lane holds 4 consecutive features (8 bytes) of each token tile; the 16-byte slot
+  // (token, 8 features) of the tiled layout is split between lanes g and g ^ 1.  v_permlane16_swap between the
+  // packed values of tile 2 tp (vdst) and tile 2 tp + 1 (src) leaves lanes with g even holding the whole slot of
+  // THEIR token of tile 2 tp and lanes with g odd that of tile 2 tp + 1 -- and the wave's 64 slots are then one
+  // whole fragment, lane-linear: 12 global_store_dwordx4 per wave instead of 24 dwordx2.  The epilogue was
+  // store-ISSUE-bound (stamps: 15-17 k cycles per tile, 46 % of the out-projection; cdna_hip_programming.md T21).
 #pragma unroll
   for (int ft = 0; ft < 6; ++ft) {
-    half4 gv, be;
-    if (EPI == EPI_BIAS_RES_LN) {
-      gv = *(const half4*)(gamma + fbase + 16 * ft);
-      be = *(const half4*)(beta + fbase + 16 * ft);
-    }
+    const half4 gv = gvs[ft], be = bes[ft];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int token = t0 + 64 * wm + 16 * tt + c16;
-      half4 o;
+    for (int tp = 0; tp < 2; ++tp) {
+      uint2 pk[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = acc[ft][tt][j];
-        if (EPI == EPI_BIAS_RES_LN) v = (v - mu[tt]) * rstd[tt] * (float)gv[j] + (float)be[j];
-        o[j] = (_Float16)v;
+      for (int u = 0; u < 2; ++u) {
+        const int tt = 2 * tp + u;
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[ft][tt][j];
+          if (EPI == EPI_BIAS_RES_LN) v = (v - mu[tt]) * rstd[tt] * (float)gv[j] + (float)be[j];
+          o[j] = (_Float16)v;
+        }
+        pk[u] = __builtin_bit_cast(uint2, o);
       }
-      if (token < M) *(half4*)(out + toff(token, fbase + 16 * ft, ldo / 16)) = o;
+      const auto sx = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+      const int token = t0 + 64 * wm + 16 * (2 * tp + (g & 1)) + c16;   // the token whose slot this lane now holds
+      if (token < M)
+        *(uint4*)(out + ((size_t)((t0 >> 5) + 2 * wm + tp) * (ldo / 16) + (n0 >> 4) + 6 * wn + ft) * 512 + lane * 8) =
+            make_uint4(sx[0], sy[0], sx[1], sy[1]);
+    }
+  }
+  if (dbg && lane == 0) {
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 512) {   // the buffer holds 4096 waves x 8 floats
+      float* d = dbg + (wg * 8 + wave) * 8;
+      const uint64_t te = __builtin_amdgcn_s_memtime();
+      d[0] = (float)(te - ts_entry);        // cycles, whole wave
+      d[1] = (float)(ts_loop - ts_entry);   // prologue (first three stages' pieces, first wait)
+      d[2] = (float)(ts_epi - ts_loop);     // the stage loop
+      d[3] = (float)t_wait;                 // of it: vmcnt wait + barrier
+      d[4] = (float)(te - ts_epi);          // epilogue
+      d[5] = (float)NST;
     }
   }
 }
@@ -1547,14 +1638,28 @@ static void launch_linear(const _Float16* X, int K, const uint4* Wt, const _Floa
   if ((rf_knob_gemm_tile & gt_bit) && tokens >= 8192) {
     const size_t lds = (size_t)GT_SLOTS * GT_STAGE_FRAGS * RF_FRAG_BYTES + RF_FRAG_BYTES + (size_t)2 * 4 * GT_TOK * 4;
     const dim3 grid((tokens + GT_TOK - 1) / GT_TOK, N / 384);
-    static rf_lds_attr attr[2];
-    if (K == 384) {
-      (void)rf_ensure_lds(attr[0], (const void*)k_gemm_tile<EPI, 24>, lds);
-      hipLaunchKernelGGL((k_gemm_tile<EPI, 24>), grid, dim3(512), lds, st, X, Wt, bias, out, N, m_ptr, res, g, b, eps);
+#define RF_GT_LAUNCH(KS_, D_)                                                                                   \
+  do {                                                                                                         \
+    static rf_lds_attr attr_;                                                                                  \
+    (void)rf_ensure_lds(attr_, (const void*)k_gemm_tile<EPI, KS_, D_>, lds);                                   \
+    hipLaunchKernelGGL((k_gemm_tile<EPI, KS_, D_>), grid, dim3(512), lds, st, X, Wt, bias, out, N, m_ptr, res, g, b, eps, gt_dbg); \
+  } while (0)
+    // clock stamps (experiments build): debug_epi 3 = the K = 1536 GEMM (FFN2), 4 = the K = 384 one (out-projection)
+    float* const gt_dbg = (rf_knob_debug_epi == (K == 384 ? 4 : 3)) ? (float*)rf_debug_buffer : nullptr;
+#ifdef RF_EXPERIMENTS
+    if (rf_knob_gemm_tile_dma == 2) {
+      if (K == 384) RF_GT_LAUNCH(24, 2);
+      else RF_GT_LAUNCH(96, 2);
+    } else
+#endif
+    if (rf_knob_gemm_tile_dma == 1) {
+      if (K == 384) RF_GT_LAUNCH(24, 1);
+      else RF_GT_LAUNCH(96, 1);
     } else {
-      (void)rf_ensure_lds(attr[1], (const void*)k_gemm_tile<EPI, 96>, lds);
-      hipLaunchKernelGGL((k_gemm_tile<EPI, 96>), grid, dim3(512), lds, st, X, Wt, bias, out, N, m_ptr, res, g, b, eps);
+      if (K == 384) RF_GT_LAUNCH(24, 0);
+      else RF_GT_LAUNCH(96, 0);
     }
+#undef RF_GT_LAUNCH
     return;
   }
   if (K == 384 && EPI != EPI_BIAS_RES_LN && rf_knob_linear_dma && tokens >= 8192) {

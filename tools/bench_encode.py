@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--tune", default="", help="rf_set_tuning pairs, e.g. ffn2_ntb=4,linear_dma=0")
     ap.add_argument("--texts", action="store_true", help="also time the text -> tokenizer -> encoder path")
     ap.add_argument("--stamps", action="store_true", help="clock stamps of the last k_linear_dma launch")
-    ap.add_argument("--stamp-epi", type=int, default=1, help="0 = QKV, 1 = FFN1, 2 = attention")
+    ap.add_argument("--stamp-epi", type=int, default=1, help="0 = QKV, 1 = FFN1, 2 = attention, 3 = FFN2, 4 = out-projection")
     ap.add_argument("--linear-dbg", type=int, default=0, help="ablation bits of k_linear_dma (results wrong)")
     args = ap.parse_args()
     import torch
@@ -86,6 +86,15 @@ def main():
                   "per item (x%.1f): QK+max %.0f, exp+sum %.0f, PV %.0f, scale+store %.0f" %
                   (ok.sum(), np.median(ntok), np.median(items), np.median(tot), np.median(stage), np.median(per),
                    np.median(qk / per), np.median(ex / per), np.median(pv / per), np.median(outp / per)))
+            return
+        if args.stamp_epi in (3, 4):   # k_gemm_tile: [workgroup][wave] x {cycles, prologue, loop, wait in loop, epilogue, stages}
+            st = buf.view(512, 8, 8).cpu().numpy()
+            ok = st[..., 0] > 0
+            tot, pro, loop, wait, epi, nst = (st[..., i][ok] for i in range(6))
+            print("k_gemm_tile stamps (last launch of the %s GEMM, %d waves): wave %.0f cycles = prologue %.0f + %d stages x %.0f "
+                  "(of which vmcnt wait + barrier %.0f) + epilogue %.0f" %
+                  ("K = 1536" if args.stamp_epi == 3 else "K = 384", ok.sum(), np.median(tot), np.median(pro), int(nst.max()),
+                   np.median(loop / nst), np.median(wait / nst), np.median(epi)))
             return
         st = buf.view(512, 8, 8).cpu().numpy()
         ok = st[..., 1] > 0

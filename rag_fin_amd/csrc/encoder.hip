@@ -224,48 +224,77 @@ __global__ void __launch_bounds__(256) k_tok_offsets(const int32_t* __restrict__
   }
 }
 
-// one wave per (sequence, position) slot; lanes 0..47 each own 8 features
+// One wave per 32 consecutive positions of one sequence: lane = (position c, feature half h), a loop over the
+// 24 16-feature groups -- the wave's stores are then runs of whole 16-byte slots of the tiled activations (a
+// token's slot of fragment f is next to its neighbour's: 512 contiguous bytes per half, split at most once by a
+// token-block boundary) instead of 48 slots 1 KiB apart per token, and the LayerNorm sums are lane-local plus
+// one xor-32 exchange.  Two sweeps over the embedding rows (statistics, then normalise and store; the second
+// one hits L2): holding a token's 384 fp32 values would take 192 registers per lane.  The per-sequence scalars
+// (length, packed offset) are wave-uniform scalar loads.  Was: one wave per token, four tokens per wave in a
+// row, each a chain of three dependent vector loads -- 49 us per 64 k-token batch.
+// KEEP = 1 (query-sized batches: latency, not throughput): ONE sweep, the 384 sums stay in registers.
+template <int KEEP>
 __global__ void __launch_bounds__(256) k_embed_ln(
     const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
     const int32_t* __restrict__ tok_off, int B, int T, int vocab, const _Float16* __restrict__ word,
     const _Float16* __restrict__ pos, const _Float16* __restrict__ type, const _Float16* __restrict__ g,
     const _Float16* __restrict__ b, float eps, _Float16* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int cpr = (T + 31) >> 5;                               // 32-position chunks per sequence row
+  const int64_t nchunks = (int64_t)B * cpr;
+  const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t slot = wave; slot < (int64_t)B * T; slot += nwaves) {
-    const int bi = (int)(slot / T), p = (int)(slot % T);
-    if (p >= min(max(lens[bi], 0), T)) continue;
-    int id = ids[slot];
+  for (int64_t ch = wave0; ch < nchunks; ch += nwaves) {       // wave-uniform
+    const int bi = (int)(ch / cpr), p0 = (int)(ch % cpr) * 32;
+    const int len = min(max(lens[bi], 0), T);
+    if (p0 >= len) continue;
+    const int p = p0 + c;
+    const bool live = p < len;
+    int id = live ? ids[(size_t)bi * T + p] : 0;
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    float v[8];
-    if (lane < 48) {
-      const half8 a = *(const half8*)(word + (size_t)id * HID + lane * 8);
-      const half8 c = *(const half8*)(pos + (size_t)p * HID + lane * 8);
-      const half8 d = *(const half8*)(type + lane * 8);
+    const _Float16* wrow = word + (size_t)id * HID + 8 * h;
+    const _Float16* prow = pos + (size_t)(live ? p : 0) * HID + 8 * h;
+    const _Float16* trow = type + 8 * h;
+    float s1 = 0.f, s2 = 0.f;
+    float keep[KEEP ? HID / 16 : 1][8];
+#pragma unroll KEEP ? 24 : 6
+    for (int f = 0; f < HID / 16; ++f) {
+      const half8 a = *(const half8*)(wrow + 16 * f);
+      const half8 cc = *(const half8*)(prow + 16 * f);
+      const half8 d = *(const half8*)(trow + 16 * f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (float)a[j] + (float)c[j] + (float)d[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const float v = (float)a[j] + (float)cc[j] + (float)d[j];
+        if (KEEP) keep[f][j] = v;
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
     }
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[j];
-    const float mu = wave_sum(s) * (1.f / HID);
-    float q = 0.f;
-    if (lane < 48) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) q += (v[j] - mu) * (v[j] - mu);
-    }
-    const float rstd = rsqrtf(wave_sum(q) * (1.f / HID) + eps);
-    if (lane < 48) {
-      const half8 gg = *(const half8*)(g + lane * 8);
-      const half8 bb = *(const half8*)(b + lane * 8);
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    const float mu = s1 * (1.f / HID);
+    // E[v^2] - mu^2 in fp32 over 384 values of order 1 with |mu| << 1: the cancellation is ~1e-6 relative
+    const float rstd = rsqrtf(fmaxf(s2 * (1.f / HID) - mu * mu, 0.f) + eps);
+    const int token = tok_off[bi] + p;
+    _Float16* orow = out + ((size_t)(token >> 5) * (HID / 16) * 64 + (size_t)h * 32 + (token & 31)) * 8;
+#pragma unroll KEEP ? 24 : 6
+    for (int f = 0; f < HID / 16; ++f) {
+      half8 a, cc, d;
+      if (!KEEP) {
+        a = *(const half8*)(wrow + 16 * f);
+        cc = *(const half8*)(prow + 16 * f);
+        d = *(const half8*)(trow + 16 * f);
+      }
+      const half8 gg = *(const half8*)(g + 16 * f + 8 * h);
+      const half8 bb = *(const half8*)(b + 16 * f + 8 * h);
       half8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (_Float16)((v[j] - mu) * rstd * (float)gg[j] + (float)bb[j]);
-      *(half8*)(out + toff(tok_off[bi] + p, lane * 8, HID / 16)) = o;
+      for (int j = 0; j < 8; ++j) {
+        const float v = KEEP ? keep[f][j] : (float)a[j] + (float)cc[j] + (float)d[j];
+        o[j] = (_Float16)((v - mu) * rstd * (float)gg[j] + (float)bb[j]);
+      }
+      if (live) *(half8*)(orow + (size_t)f * 512) = o;
     }
   }
 }
@@ -1293,7 +1322,7 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
     // Staging: thread = (16-byte part of a row, row mod 64).  ALL of a thread's global loads are issued
     // before the first LDS write (one row per loop trip, load -> wait -> write, paid the HBM latency up to
     // eight times in a row).
-    constexpr int RI = KB / 2;   // rows rl + 64 i, i < RI, cover the TP rows
+    constexpr int RI = (KB + 1) / 2;   // rows rl + 64 i, i < RI, cover the TP rows (KB = 1: the first 32 of them)
     const int part = tid & 3, rl = tid >> 2;
     half8 kreg[NH][RI], vreg[NH][RI];
 #pragma unroll
@@ -1313,11 +1342,13 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
 #pragma unroll
       for (int i = 0; i < RI; ++i) {
         const int row = rl + 64 * i;
-        _Float16* ks_w = lds_h + hh * head_lds;
-        _Float16* vt_w = ks_w + (size_t)TP * 40;
-        *(half8*)(ks_w + row * 40 + part * 8) = kreg[hh][i];
+        if (row < TP) {
+          _Float16* ks_w = lds_h + hh * head_lds;
+          _Float16* vt_w = ks_w + (size_t)TP * 40;
+          *(half8*)(ks_w + row * 40 + part * 8) = kreg[hh][i];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vt_w[(part * 8 + e) * vstride + row] = vreg[hh][i][e];
+          for (int e = 0; e < 8; ++e) vt_w[(part * 8 + e) * vstride + row] = vreg[hh][i][e];
+        }
       }
   }
   __syncthreads();
@@ -1352,7 +1383,8 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
     // states an XDL write needs before a VALU read (11 for the 8-pass 32x32x16) are supplied by hand -- ONE
     // block of nops that takes every accumulator as an in/out operand, so that it cannot be scheduled above
     // any of the products.
-    if constexpr (KB == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]));
+    if constexpr (KB == 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]));
+    else if constexpr (KB == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]));
     else if constexpr (KB == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
     else if constexpr (KB == 6)
       asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]));
@@ -1810,34 +1842,41 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
 
   hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off);
   {
-    int64_t waves = (int64_t)B * T;
+    int64_t waves = (int64_t)B * ((T + 31) / 32);   // one wave per 32 positions of a row
     int grid = (int)((waves + 3) / 4);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_embed_ln, dim3(grid), dim3(256), 0, st, ids_dev, lens_dev, ws.tok_off, B, T,
-                       c.vocab_size, (const _Float16*)w.word_emb, (const _Float16*)w.pos_emb,
-                       (const _Float16*)w.type_emb, (const _Float16*)w.emb_ln_g,
-                       (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
+    if (waves <= 64)   // query-sized: one sweep, sums kept in registers
+      hipLaunchKernelGGL(k_embed_ln<1>, dim3(grid), dim3(256), 0, st, ids_dev, lens_dev, ws.tok_off, B, T,
+                         c.vocab_size, (const _Float16*)w.word_emb, (const _Float16*)w.pos_emb,
+                         (const _Float16*)w.type_emb, (const _Float16*)w.emb_ln_g,
+                         (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
+    else
+      hipLaunchKernelGGL(k_embed_ln<0>, dim3(grid), dim3(256), 0, st, ids_dev, lens_dev, ws.tok_off, B, T,
+                         c.vocab_size, (const _Float16*)w.word_emb, (const _Float16*)w.pos_emb,
+                         (const _Float16*)w.type_emb, (const _Float16*)w.emb_ln_g,
+                         (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
   }
   const size_t attn_lds = (size_t)T * 2 * HEAD_DIM * 2;
   static rf_lds_attr attn_attr;
   if (T > 32 * ATT_MAX_KB) RF_HIP(rf_ensure_lds(attn_attr, (const void*)k_attention, attn_lds));
   // instantiation by the batch's width: <key blocks, minimum waves per SIMD the register budget must allow, heads
   // per workgroup>
-  const int att_kb = T <= 64 ? 2 : (T <= 128 ? 4 : (T <= 192 ? 6 : 8));
+  const int att_kb = T <= 32 ? 1 : (T <= 64 ? 2 : (T <= 128 ? 4 : (T <= 192 ? 6 : 8)));   // a query is one key block
   const int att_nh = rf_knob_att_heads;
   const size_t att_tp = (size_t)att_kb * 32;   // the kernel's LDS image has the instantiation's shape
   const size_t mfma_lds = att_nh * (att_tp * 80 + (size_t)32 * (att_tp + 4) * 2);  // 37 KB per head at T = 256
-  static rf_lds_attr mfma_attrs[8];
 #define RF_ATT_CASE(KB_, W2, W1)                                                                                  \
-  case KB_:                                                                                                      \
+  case KB_: {                                                                                                    \
+    static rf_lds_attr a2_, a1_;   /* per instantiation, per device */                                           \
     if (att_nh == 2) {                                                                                           \
-      RF_HIP(rf_ensure_lds(mfma_attrs[KB_ - 2], (const void*)k_attention_mfma<KB_, W2, 2>, mfma_lds));           \
+      RF_HIP(rf_ensure_lds(a2_, (const void*)k_attention_mfma<KB_, W2, 2>, mfma_lds));                           \
     } else {                                                                                                     \
-      RF_HIP(rf_ensure_lds(mfma_attrs[KB_ - 1], (const void*)k_attention_mfma<KB_, W1, 1>, mfma_lds));           \
+      RF_HIP(rf_ensure_lds(a1_, (const void*)k_attention_mfma<KB_, W1, 1>, mfma_lds));                           \
     }                                                                                                            \
-    break;
+  } break;
   if (T <= 32 * ATT_MAX_KB) {
     switch (att_kb) {
+      RF_ATT_CASE(1, 4, 6)
       RF_ATT_CASE(2, 4, 6)
       RF_ATT_CASE(4, 3, 4)
       RF_ATT_CASE(6, 2, 3)
@@ -1866,6 +1905,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
       hipLaunchKernelGGL((k_attention_mfma<KB_, W1, 1>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx, att_dbg); \
     break;
       switch (att_kb) {
+        RF_ATT_CASE(1, 4, 6)
         RF_ATT_CASE(2, 4, 6)
         RF_ATT_CASE(4, 3, 4)
         RF_ATT_CASE(6, 2, 3)

@@ -14,12 +14,19 @@
 // Kernels
 //   k_tok_offsets   lens -> packed row offsets
 //   k_embed_ln      word + position + type embedding gather, LayerNorm        (K1)
-//   k_linear<EPI>   Y^T = W X^T on the matrix cores: a workgroup owns 32 or 64 tokens x
-//                   384 output features (4 waves x 96); epilogues fused:
-//                   bias (QKV, K2) | bias+GELU (K5) | bias+residual+LayerNorm (K4, K6)
+//   the Linears     Y^T = W X^T on the matrix cores with the epilogues fused -- bias (QKV, K2) | bias + GELU
+//                   (K5) | bias + residual + LayerNorm (K4, K6) -- in one of four forms chosen by the batch's
+//                   token slots (launch_linear):
+//     k_linear_small  <= 1024 slots (queries): output features spread over the chip, LayerNorm as k_ln_rows
+//     k_linear        < 8192: a workgroup owns 32 or 64 tokens x 384 features, operands straight from L1/L2
+//     k_linear_dma    >= 8192, QKV and FFN1: the wave's 32 tokens resident in registers, weights through an
+//                     LDS-DMA ring, the epilogue of block b deferred into the MFMA stream of block b + 1
+//     k_gemm_tile     >= 8192, out-projection and FFN2 (LayerNorm epilogues): both operands through a 4-slot
+//                     LDS-DMA ring, 128 tokens x 384 features per workgroup
 //   k_attention_mfma softmax(Q K^T / sqrt(32)) V per (sequence, head) on the matrix cores
 //                   for T <= 256 (K3); k_attention = vector-ALU online-softmax form
 //                   kept for longer sequences
+//   k_qkv_attn_one  a single sequence of <= 32 tokens: K2 + K3 of a head in one launch
 //   k_pool_norm     mean over the sequence, L2-normalise                      (K7)
 #include "rf_internal.h"
 #include "lds_ring.h"
@@ -1232,6 +1239,118 @@ __global__ void __launch_bounds__(256) k_linear_small(
   }
 }
 
+// ONE query (a single sequence of <= 32 tokens: the reference's serving mode): the QKV projection of a head
+// and its attention in one launch, one workgroup per head.  The four waves split the K range of the three
+// 32-feature blocks (Q, K, V of the head) as k_linear_small does, the partial sums meet in LDS, and wave 0
+// finishes them straight into MFMA operands -- no activation leaves the workgroup:
+//   Q, K:  A = weights, B = tokens  -> the accumulator holds the TOKEN on the lane and the head's dims in
+//          registers; registers 8 s .. 8 s + 7 of both, as fp16, are the operands of S^T = K Q^T for k-step s
+//          (the dims come in the accumulator's order in both: a dot product does not care);
+//   V:     A = tokens, B = weights  -> the accumulator holds the DIM on the lane and tokens in registers:
+//          V^T, whose registers 8 s .. 8 s + 7 are the A operand of O^T = V^T P in the key order of the
+//          probability accumulator (16 s + 8 (e >> 2) + 4 h + (e & 3)).
+// Same arithmetic as k_linear_small + k_attention_mfma (fp32 sums in the same order, bias, fp16 rounding of
+// Q / K / V, fp32 softmax), six launches fewer per forward (~5 us each on the 45-launch dependency chain).
+__global__ void __launch_bounds__(256) k_qkv_attn_one(const _Float16* __restrict__ X, const uint4* __restrict__ Wt,
+                                                      const _Float16* __restrict__ bias,
+                                                      const int32_t* __restrict__ m_ptr, _Float16* __restrict__ ctx) {
+  constexpr int KS = HID / 16, KW = KS / 4;   // 24 k-steps, 6 per wave
+  typedef float f32x4r __attribute__((ext_vector_type(4)));
+  __shared__ f32x4r red[4][3][4][64];         // [wave][q | k | v][register quad][lane]: 48 KB
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const int head = blockIdx.x;
+  constexpr int NHEADS = HID / HEAD_DIM;
+  uint4 wf[3][KW];
+  half8 xf[KW];
+#pragma unroll
+  for (int r = 0; r < KW; ++r) {
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk)
+      wf[blk][r] = Wt[((size_t)(blk * NHEADS + head) * KS + wave * KW + r) * 64 + lane];
+    xf[r] = *(const half8*)(X + ((size_t)(wave * KW + r) * 64 + lane) * 8);
+  }
+  f32x16 acc[3];
+#pragma unroll
+  for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[blk][i] = 0.f;
+#pragma unroll
+  for (int r = 0; r < KW; ++r) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wf[0][r]), xf[r], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, wf[1][r]), xf[r], acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[r], __builtin_bit_cast(half8, wf[2][r]), acc[2], 0, 0, 0);
+  }
+#pragma unroll
+  for (int blk = 0; blk < 3; ++blk)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      red[wave][blk][q][lane] = f32x4r{acc[blk][4 * q], acc[blk][4 * q + 1], acc[blk][4 * q + 2], acc[blk][4 * q + 3]};
+  __syncthreads();
+  if (wave != 0) return;
+  int n = *m_ptr;
+  n = n < 0 ? 0 : (n > 32 ? 32 : n);
+  // full sums + bias -> fp16 operands.  Q / K: register 4 q + j = feature 8 q + 4 h + j; V^T: lane = feature c
+  half8 qf[2], kf[2], vf[2];
+  const float bvt = (float)bias[(2 * NHEADS + head) * HEAD_DIM + c];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4r sq = (red[0][0][q][lane] + red[1][0][q][lane]) + (red[2][0][q][lane] + red[3][0][q][lane]);
+    f32x4r sk = (red[0][1][q][lane] + red[1][1][q][lane]) + (red[2][1][q][lane] + red[3][1][q][lane]);
+    f32x4r sv = (red[0][2][q][lane] + red[1][2][q][lane]) + (red[2][2][q][lane] + red[3][2][q][lane]);
+    const half4 bq = *(const half4*)(bias + head * HEAD_DIM + 8 * q + 4 * h);
+    const half4 bk = *(const half4*)(bias + (NHEADS + head) * HEAD_DIM + 8 * q + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qf[q >> 1][4 * (q & 1) + j] = (_Float16)(sq[j] + (float)bq[j]);
+      kf[q >> 1][4 * (q & 1) + j] = (_Float16)(sk[j] + (float)bk[j]);
+      // V^T register 4 q + j = token 8 q + 4 h + j: rows beyond the sequence are whatever the activation buffer
+      // held (their probabilities are exactly 0 -- but 0 x NaN is not)
+      vf[q >> 1][4 * (q & 1) + j] = (8 * q + 4 * h + j < n) ? (_Float16)(sv[j] + bvt) : (_Float16)0.f;
+    }
+  }
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0], z, 0, 0, 0);
+  sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[1], sc, 0, 0, 0);
+  // lane = query c, register i = key 8 (i >> 2) + 4 h + (i & 3)
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if ((i & 3) + 8 * (i >> 2) + 4 * h >= n) sc[i] = -INFINITY;
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m = fmaxf(m, sc[i]);
+  m = fmaxf(m, __shfl_xor(m, 32));
+  const float c2 = 0.17677669529663687f * 1.4426950408889634f;   // exp(scale (s - m)) = exp2(c2 s - c2 m)
+  const float mc = m * c2;
+  float l = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    sc[i] = __builtin_amdgcn_exp2f(fmaf(sc[i], c2, -mc));
+    l += sc[i];
+  }
+  l += __shfl_xor(l, 32);
+  f32x16 o = z;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    half8 pb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pb[j] = (_Float16)sc[8 * s + j];
+    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s], pb, o, 0, 0, 0);
+  }
+  if (c < n) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      half4 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = (_Float16)(o[4 * g + j] * inv);
+      *(half4*)(ctx + toff(c, head * HEAD_DIM + 8 * g + 4 * h, HID / 16)) = t;
+    }
+  }
+}
+
 // LayerNorm of fp32 rows [token][384] -> fp16 tiled activations; one wave per token
 // (the LayerNorm of the small-batch path.  Tried and dropped: the GEMM's last-arriving workgroup
 // normalising the rows behind agent-scope fences and one atomic -- 250 vs 222 us per 12-token
@@ -1886,6 +2005,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
   }
 #undef RF_ATT_CASE
   float* const att_dbg = (rf_knob_debug_epi == 2) ? (float*)rf_debug_buffer : nullptr;   // clock stamps (experiments build)
+  const bool one_query = rf_knob_one_query && B == 1 && T <= 32 && rf_knob_linear_small;
   _Float16* x = ws.x;
   _Float16* y = ws.y;
   for (int l = 0; l < L; ++l) {
@@ -1893,6 +2013,10 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
     const uint4* ao_t = enc->ao_t + (size_t)l * HID * HID / 8;
     const uint4* ff1_t = enc->ff1_t + (size_t)l * I * HID / 8;
     const uint4* ff2_t = enc->ff2_t + (size_t)l * HID * I / 8;
+    if (one_query) {   // a single sequence of <= 32 tokens: QKV projection and attention of a head in one launch
+      hipLaunchKernelGGL(k_qkv_attn_one, dim3(c.heads), dim3(256), 0, st, x, qkv_t,
+                         (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, m_ptr, ws.ctx);
+    } else {
     launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
                             3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
     if (T <= 32 * ATT_MAX_KB) {
@@ -1917,6 +2041,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
     else
       hipLaunchKernelGGL(k_attention, dim3(B, c.heads), dim3(256), attn_lds, st, ws.qkv, ws.tok_off,
                          ws.ctx);
+    }
     launch_linear<EPI_BIAS_RES_LN>(ws.ctx, HID, ao_t, (const _Float16*)w.ao_b + (size_t)l * HID, y, HID,
                                    tiles, m_ptr, x, (const _Float16*)w.ln1_g + (size_t)l * HID,
                                    (const _Float16*)w.ln1_b + (size_t)l * HID, c.ln_eps, ws.pre, st);

@@ -72,7 +72,7 @@ def test_search_top5_equals_oracle_on_stored_vectors(rig):
 
 
 NORTH_STAR_TOL = 1e-3     # BASELINE.json north_star: "scores within 1e-3 fp16"
-MEASURED_TOL = 4.5e-4     # 3 x the 1.5e-4 measured over all pairs (profiles/r02a_encoder_error.json)
+MEASURED_TOL = 4.5e-4     # <= 3 x the 1.5e-4 .. 1.7e-4 measured over all pairs (profiles/r02a_encoder_error.json, r02zz_encoder_error.json)
 
 
 def test_north_star_gpu_pipeline_vs_all_cpu_pipeline(rig):

@@ -1385,7 +1385,7 @@ __device__ __forceinline__ float att_max3(float a, float b, float c) {
 // scores of a (query block, head) item stay in registers between the two products -- 16 KB registers -- and
 // the kernel is latency-bound (10 % matrix pipe busy), so short batches (the ingest buckets are sorted by
 // length) take an instantiation with fewer registers and more waves per SIMD instead of the T = 256 one.
-template <int KB, int WPS, int NH>   // NH = heads per workgroup (1 | 2)
+template <int KB, int WPS, int NH, int NHALF>   // NH = heads per workgroup (1 | 2); NHALF = groups the key blocks are taken in
 __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __restrict__ qkv,
                                                         const int32_t* __restrict__ tok_off,
                                                         _Float16* __restrict__ ctx, float* __restrict__ dbg) {
@@ -1484,113 +1484,135 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
     int hh_nxt = hh_cur, qb_nxt = qb_cur;
     advance(hh_nxt, qb_nxt);
     load_q(hh_nxt, qb_nxt, qn);
-    f32x16 sc[KB];
-    // S^T = K Q^T for EVERY key block of the instantiation, back to back (rows beyond the sequence are zero in
-    // LDS): no branch between the LDS reads and the products, so the reads are issued ahead and the products
-    // pipeline.  (Per block behind `kb < nkb` branches, with the running maximum inside, each block was a
-    // serial chain read -> 2 MFMAs -> drain -> 8 v_max3 of ~430 cycles: stamps.)  Raw scores stay in the
-    // accumulator; the 1/sqrt(32) scale is folded into the exponent below.
+    // The key blocks are taken in NHALF groups of HB (online softmax: running maximum m_run, running row sum
+    // l_run, the output accumulator rescaled when the maximum moves).  NHALF = 2 for the long instantiations:
+    // the scores of a group, not of the whole sequence, stay in registers -- 64 instead of 128 at T = 256 -- and
+    // a fourth workgroup fits the CU's registers (the kernel's time is waiting, not issue: DESIGN.md 4.5).
+    constexpr int HB = KB / NHALF;
+    static_assert(HB * NHALF == KB, "key blocks per group");
+    const float c2 = scale * 1.4426950408889634f;   // exp(scale * (s - m)) = exp2(c2 * s - c2 * m)
+    float m_run = -INFINITY;
+    f32x2 l2 = {0.f, 0.f};                          // lane-partial row sum (the two halves of a query's keys meet at the end)
+    f32x16 o;
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const half8 a0 = *(const half8*)(ks + (kb * 32 + c) * 40 + 8 * h);
-      const half8 a1 = *(const half8*)(ks + (kb * 32 + c) * 40 + 16 + 8 * h);
-      sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[0], z, 0, 0, 0);
-      sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[1], sc[kb], 0, 0, 0);
-    }
-    // att_max3 is inline asm, which hipcc's hazard recognizer does not see reading the MFMA result: the wait
-    // states an XDL write needs before a VALU read (11 for the 8-pass 32x32x16) are supplied by hand -- ONE
-    // block of nops that takes every accumulator as an in/out operand, so that it cannot be scheduled above
-    // any of the products.
-    if constexpr (KB == 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]));
-    else if constexpr (KB == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]));
-    else if constexpr (KB == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
-    else if constexpr (KB == 6)
-      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]));
-    else
-      asm volatile("s_nop 7\n\ts_nop 7"
-                   : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]), "+v"(sc[6]), "+v"(sc[7]));
-    // key >= n -> -inf: only in the block(s) that hold padding, behind a wave-uniform branch (the empty asm
-    // keeps the compiler from turning the branch into 16 selects per block of EVERY item)
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
     int lim = n - 4 * h;                 // the lane's keys 32 kb + 8 (i >> 2) + (i & 3) >= lim are padding
     asm volatile("" : "+v"(lim));        // opaque per item: as a loop invariant the 16 x KB compares were hoisted
                                          // into 128 live lane masks (and spilled)
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if ((kb + 1) * 32 > n) {
+    for (int hf = 0; hf < NHALF; ++hf) {
+      const int kb0 = hf * HB;
+      if (hf > 0 && kb0 >= nkb) break;   // wave-uniform: the sequence ends before this group
+      f32x16 sc[HB];
+      // S^T = K Q^T for EVERY key block of the group, back to back (rows beyond the sequence are zero in LDS): no
+      // branch between the LDS reads and the products, so the reads are issued ahead and the products pipeline.
+      // (Per block behind `kb < nkb` branches, with the running maximum inside, each block was a serial chain
+      // read -> 2 MFMAs -> drain -> 8 v_max3 of ~430 cycles: stamps.)  Raw scores stay in the accumulator; the
+      // 1/sqrt(32) scale is folded into the exponent below.
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (kb * 32 + (i & 3) + 8 * (i >> 2) >= lim) sc[kb][i] = -INFINITY;
+      for (int kk = 0; kk < HB; ++kk) {
+        const int kb = kb0 + kk;
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const half8 a0 = *(const half8*)(ks + (kb * 32 + c) * 40 + 8 * h);
+        const half8 a1 = *(const half8*)(ks + (kb * 32 + c) * 40 + 16 + 8 * h);
+        sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[0], z, 0, 0, 0);
+        sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[1], sc[kk], 0, 0, 0);
       }
-    }
-    // running maximum by v_max3_f32 (two new elements per instruction) over the blocks the sequence has
-    float m = -INFINITY;
+      // att_max3 is inline asm, which hipcc's hazard recognizer does not see reading the MFMA result: the wait
+      // states an XDL write needs before a VALU read (11 for the 8-pass 32x32x16) are supplied by hand -- ONE
+      // block of nops that takes every accumulator as an in/out operand, so that it cannot be scheduled above
+      // any of the products.
+      if constexpr (HB == 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]));
+      else if constexpr (HB == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]));
+      else if constexpr (HB == 3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]));
+      else if constexpr (HB == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
+      else if constexpr (HB == 6)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]));
+      else
+        asm volatile("s_nop 7\n\ts_nop 7"
+                     : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]), "+v"(sc[6]), "+v"(sc[7]));
+      // key >= n -> -inf: only in the block(s) that hold padding, behind a wave-uniform branch
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb < nkb) {
+      for (int kk = 0; kk < HB; ++kk) {
+        const int kb = kb0 + kk;
+        if ((kb + 1) * 32 > n) {
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) m = att_max3(m, sc[kb][i], sc[kb][i + 1]);
+          for (int i = 0; i < 16; ++i)
+            if (kb * 32 + (i & 3) + 8 * (i >> 2) >= lim) sc[kk][i] = -INFINITY;
+        }
       }
-    }
-    m = fmaxf(m, __shfl_xor(m, 32));
-    if (dbg) {
-      asm volatile("" : "+v"(m));
-      tb = __builtin_amdgcn_s_memtime();
-      t_qk += tb - ta;
-      ta = tb;
-    }
-    f32x2 l2 = {0.f, 0.f};
-    const float c2 = scale * 1.4426950408889634f;   // exp(scale * (s - m)) = exp2(c2 * s - c2 * m)
-    const float mc = m * c2;
+      // maximum by v_max3_f32 (two new elements per instruction) over the blocks the sequence has
+      float m = m_run;
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb < nkb) {
-        // exponent argument and row sum on PAIRS (v_pk_fma_f32 / v_pk_add_f32: two floats per
-        // lane at the single rate); v_exp_f32 is the transcendental pipe either way
+      for (int kk = 0; kk < HB; ++kk) {
+        if (kb0 + kk < nkb) {
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          f32x2 e;
-          e[0] = sc[kb][i];
-          e[1] = sc[kb][i + 1];
-          e = __builtin_elementwise_fma(e, f32x2{c2, c2}, f32x2{-mc, -mc});
-          f32x2 pr;
-          pr[0] = __builtin_amdgcn_exp2f(e[0]);
-          pr[1] = __builtin_amdgcn_exp2f(e[1]);
-          sc[kb][i] = pr[0];
-          sc[kb][i + 1] = pr[1];
-          l2 += pr;
+          for (int i = 0; i < 16; i += 2) m = att_max3(m, sc[kk][i], sc[kk][i + 1]);
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (dbg) {
+        asm volatile("" : "+v"(m));
+        tb = __builtin_amdgcn_s_memtime();
+        t_qk += tb - ta;
+        ta = tb;
+      }
+      const float mc = m * c2;
+      if (hf > 0) {   // the maximum may have moved: what was accumulated so far is rescaled (exp2(-inf) = 0 never occurs: m_run is finite here)
+        const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, c2, -mc));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] *= alpha;
+        l2 *= f32x2{alpha, alpha};
+      }
+      m_run = m;
+#pragma unroll
+      for (int kk = 0; kk < HB; ++kk) {
+        if (kb0 + kk < nkb) {
+          // exponent argument and row sum on PAIRS (v_pk_fma_f32 / v_pk_add_f32: two floats per
+          // lane at the single rate); v_exp_f32 is the transcendental pipe either way
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            f32x2 e;
+            e[0] = sc[kk][i];
+            e[1] = sc[kk][i + 1];
+            e = __builtin_elementwise_fma(e, f32x2{c2, c2}, f32x2{-mc, -mc});
+            f32x2 pr;
+            pr[0] = __builtin_amdgcn_exp2f(e[0]);
+            pr[1] = __builtin_amdgcn_exp2f(e[1]);
+            sc[kk][i] = pr[0];
+            sc[kk][i + 1] = pr[1];
+            l2 += pr;
+          }
+        }
+      }
+      if (dbg) {
+        asm volatile("" : "+v"(l2));
+        tb = __builtin_amdgcn_s_memtime();
+        t_exp += tb - ta;
+        ta = tb;
+      }
+#pragma unroll
+      for (int kk = 0; kk < HB; ++kk) {
+        const int kb = kb0 + kk;
+        if (kb < nkb) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            half8 pb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[j] = (_Float16)sc[kk][8 * s + j];
+            const _Float16* vrow = vt + c * vstride + kb * 32 + 16 * s + 4 * h;  // c = head dim here
+            const half4 lo = *(const half4*)vrow;
+            const half4 hi = *(const half4*)(vrow + 8);
+            half8 a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb, o, 0, 0, 0);
+          }
         }
       }
     }
     float l = l2[0] + l2[1];
     l += __shfl_xor(l, 32);
-    if (dbg) {
-      asm volatile("" : "+v"(l));
-      tb = __builtin_amdgcn_s_memtime();
-      t_exp += tb - ta;
-      ta = tb;
-    }
-    f32x16 o;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb < nkb) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          half8 pb;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pb[j] = (_Float16)sc[kb][8 * s + j];
-          const _Float16* vrow = vt + c * vstride + kb * 32 + 16 * s + 4 * h;  // c = head dim here
-          const half4 lo = *(const half4*)vrow;
-          const half4 hi = *(const half4*)(vrow + 8);
-          half8 a;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb, o, 0, 0, 0);
-        }
-      }
-    }
     if (dbg) {
       asm volatile("s_nop 7\n\ts_nop 7" : "+v"(o));
       tb = __builtin_amdgcn_s_memtime();
@@ -1984,22 +2006,22 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
   const int att_nh = rf_knob_att_heads;
   const size_t att_tp = (size_t)att_kb * 32;   // the kernel's LDS image has the instantiation's shape
   const size_t mfma_lds = att_nh * (att_tp * 80 + (size_t)32 * (att_tp + 4) * 2);  // 37 KB per head at T = 256
-#define RF_ATT_CASE(KB_, W2, W1)                                                                                  \
+#define RF_ATT_CASE(KB_, W2, W1, NHF)                                                                                \
   case KB_: {                                                                                                    \
     static rf_lds_attr a2_, a1_;   /* per instantiation, per device */                                           \
     if (att_nh == 2) {                                                                                           \
-      RF_HIP(rf_ensure_lds(a2_, (const void*)k_attention_mfma<KB_, W2, 2>, mfma_lds));                           \
+      RF_HIP(rf_ensure_lds(a2_, (const void*)k_attention_mfma<KB_, W2, 2, NHF>, mfma_lds));                           \
     } else {                                                                                                     \
-      RF_HIP(rf_ensure_lds(a1_, (const void*)k_attention_mfma<KB_, W1, 1>, mfma_lds));                           \
+      RF_HIP(rf_ensure_lds(a1_, (const void*)k_attention_mfma<KB_, W1, 1, NHF>, mfma_lds));                           \
     }                                                                                                            \
   } break;
   if (T <= 32 * ATT_MAX_KB) {
     switch (att_kb) {
-      RF_ATT_CASE(1, 4, 6)
-      RF_ATT_CASE(2, 4, 6)
-      RF_ATT_CASE(4, 3, 4)
-      RF_ATT_CASE(6, 2, 3)
-      RF_ATT_CASE(8, 2, 3)
+      RF_ATT_CASE(1, 4, 6, 1)
+      RF_ATT_CASE(2, 4, 6, 1)
+      RF_ATT_CASE(4, 3, 4, 1)
+      RF_ATT_CASE(6, 3, 4, 2)
+      RF_ATT_CASE(8, 3, 4, 2)
       default: break;
     }
   }
@@ -2021,19 +2043,19 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
                             3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
     if (T <= 32 * ATT_MAX_KB) {
       const dim3 ag(B, c.heads / att_nh);
-#define RF_ATT_CASE(KB_, W2, W1)                                                                                          \
+#define RF_ATT_CASE(KB_, W2, W1, NHF)                                                                                        \
   case KB_:                                                                                                              \
     if (att_nh == 2)                                                                                                     \
-      hipLaunchKernelGGL((k_attention_mfma<KB_, W2, 2>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx, att_dbg); \
+      hipLaunchKernelGGL((k_attention_mfma<KB_, W2, 2, NHF>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx, att_dbg); \
     else                                                                                                                 \
-      hipLaunchKernelGGL((k_attention_mfma<KB_, W1, 1>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx, att_dbg); \
+      hipLaunchKernelGGL((k_attention_mfma<KB_, W1, 1, NHF>), ag, dim3(256), mfma_lds, st, ws.qkv, ws.tok_off, ws.ctx, att_dbg); \
     break;
       switch (att_kb) {
-        RF_ATT_CASE(1, 4, 6)
-        RF_ATT_CASE(2, 4, 6)
-        RF_ATT_CASE(4, 3, 4)
-        RF_ATT_CASE(6, 2, 3)
-        RF_ATT_CASE(8, 2, 3)
+        RF_ATT_CASE(1, 4, 6, 1)
+        RF_ATT_CASE(2, 4, 6, 1)
+        RF_ATT_CASE(4, 3, 4, 1)
+        RF_ATT_CASE(6, 3, 4, 2)
+        RF_ATT_CASE(8, 3, 4, 2)
         default: break;
       }
 #undef RF_ATT_CASE

@@ -1028,41 +1028,63 @@ __global__ void __launch_bounds__(512, 1) k_gemm_tile(
       }
     }
   }
+  uint64_t ts_e1 = 0, ts_e2 = 0;
+  if (dbg) {
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[5][3]));
+    ts_e1 = __builtin_amdgcn_s_memtime();   // bias + residual added: the epilogue's loads have arrived
+  }
   if (EPI == EPI_BIAS_RES_LN) {
-    // LayerNorm over the 384 features of a token: 24 per lane, x 4 lane groups (g), x 4 feature quarters
+    // LayerNorm over the 384 features of a token: 24 per lane, x 4 lane groups (g), x 4 feature quarters.  Sum and
+    // sum of squares in ONE sweep and ONE exchange through LDS (variance = E[x^2] - mean^2 in fp32: the inputs
+    // are residual-stream values of order 1 with |mean| << spread, the cancellation costs ~1e-6 relative): the
+    // two-sweep form had a second barrier and a second LDS round trip on every workgroup's critical path.
+    // (The cross-lane sums stay __shfl_xor: as v_permlane16/32_swap pair sums they measured 4 600 against 5 000
+    // cycles for this block -- and the BUILTIN fed one value twice is folded by hipcc 7.2 into x + x, wrong
+    // statistics with no diagnostic; only the inline-asm form is usable for that.)
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int tt = 0; tt < 4; ++tt) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        float sum = 0.f;
+      for (int ft = 0; ft < 6; ++ft)
 #pragma unroll
-        for (int ft = 0; ft < 6; ++ft)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float d = pass ? acc[ft][tt][j] - mu[tt] : acc[ft][tt][j];
-            sum += pass ? d * d : d;
-          }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        if (g == 0) red[(pass * 4 + wn) * GT_TOK + 64 * wm + 16 * tt + c16] = sum;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int tk = 64 * wm + 16 * tt + c16;
-        const float tot = (red[(pass * 4 + 0) * GT_TOK + tk] + red[(pass * 4 + 1) * GT_TOK + tk]) +
-                          (red[(pass * 4 + 2) * GT_TOK + tk] + red[(pass * 4 + 3) * GT_TOK + tk]);
-        if (pass == 0) mu[tt] = tot * (1.f / HID);
-        else rstd[tt] = rsqrtf(tot * (1.f / HID) + eps);
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[ft][tt][j];
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (g == 0) {
+        red[(0 * 4 + wn) * GT_TOK + 64 * wm + 16 * tt + c16] = s1;
+        red[(1 * 4 + wn) * GT_TOK + 64 * wm + 16 * tt + c16] = s2;
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int tk = 64 * wm + 16 * tt + c16;
+      const float t1 = (red[(0 * 4 + 0) * GT_TOK + tk] + red[(0 * 4 + 1) * GT_TOK + tk]) +
+                       (red[(0 * 4 + 2) * GT_TOK + tk] + red[(0 * 4 + 3) * GT_TOK + tk]);
+      const float t2 = (red[(1 * 4 + 0) * GT_TOK + tk] + red[(1 * 4 + 1) * GT_TOK + tk]) +
+                       (red[(1 * 4 + 2) * GT_TOK + tk] + red[(1 * 4 + 3) * GT_TOK + tk]);
+      mu[tt] = t1 * (1.f / HID);
+      rstd[tt] = rsqrtf(fmaxf(t2 * (1.f / HID) - mu[tt] * mu[tt], 0.f) + eps);
+    }
+  }
+  if (dbg) {
+    asm volatile("" : "+v"(mu[0]), "+v"(rstd[3]));
+    ts_e2 = __builtin_amdgcn_s_memtime();   // LayerNorm statistics known
   }
   // Stores: 16 bytes per lane.  A lane holds 4 consecutive features (8 bytes) of each token tile; the 16-byte slot
   // (token, 8 features) of the tiled layout is split between lanes g and g ^ 1.  v_permlane16_swap between the
   // packed values of tile 2 tp (vdst) and tile 2 tp + 1 (src) leaves lanes with g even holding the whole slot of
   // THEIR token of tile 2 tp and lanes with g odd that of tile 2 tp + 1 -- and the wave's 64 slots are then one
-  // whole fragment, lane-linear: 12 global_store_dwordx4 per wave instead of 24 dwordx2.  The epilogue was
-  // store-ISSUE-bound (stamps: 15-17 k cycles per tile, 46 % of the out-projection; cdna_hip_programming.md T21).
+  // whole fragment, lane-linear: 12 global_store_dwordx4 per wave instead of 24 dwordx2 (cdna_hip_programming.md
+  // T21; here worth little by itself -- the epilogue's 12-13 k cycles per tile are a memory round trip for the
+  // residual (4-5 k), the LayerNorm statistics with their shuffles, LDS exchange and barrier (5 k) and the
+  // normalise + store pass (3 k): stamps).
 #pragma unroll
   for (int ft = 0; ft < 6; ++ft) {
     const half4 gv = gvs[ft], be = bes[ft];
@@ -1100,6 +1122,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm_tile(
       d[3] = (float)t_wait;                 // of it: vmcnt wait + barrier
       d[4] = (float)(te - ts_epi);          // epilogue
       d[5] = (float)NST;
+      d[6] = (float)(ts_e1 - ts_epi);       // of the epilogue: until bias + residual are in
+      d[7] = (float)(ts_e2 - ts_e1);        // ... the LayerNorm statistics (the rest: normalise + store)
     }
   }
 }

@@ -90,11 +90,13 @@ def main():
         if args.stamp_epi in (3, 4):   # k_gemm_tile: [workgroup][wave] x {cycles, prologue, loop, wait in loop, epilogue, stages}
             st = buf.view(512, 8, 8).cpu().numpy()
             ok = st[..., 0] > 0
-            tot, pro, loop, wait, epi, nst = (st[..., i][ok] for i in range(6))
+            tot, pro, loop, wait, epi, nst, e1, e2 = (st[..., i][ok] for i in range(8))
             print("k_gemm_tile stamps (last launch of the %s GEMM, %d waves): wave %.0f cycles = prologue %.0f + %d stages x %.0f "
-                  "(of which vmcnt wait + barrier %.0f) + epilogue %.0f" %
+                  "(of which vmcnt wait + barrier %.0f) + epilogue %.0f (loads + bias + residual %.0f, LayerNorm statistics %.0f, "
+                  "normalise + store %.0f)" %
                   ("K = 1536" if args.stamp_epi == 3 else "K = 384", ok.sum(), np.median(tot), np.median(pro), int(nst.max()),
-                   np.median(loop / nst), np.median(wait / nst), np.median(epi)))
+                   np.median(loop / nst), np.median(wait / nst), np.median(epi), np.median(e1), np.median(e2),
+                   np.median(epi - e1 - e2)))
             return
         st = buf.view(512, 8, 8).cpu().numpy()
         ok = st[..., 1] > 0

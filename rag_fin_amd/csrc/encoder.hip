@@ -569,11 +569,17 @@ __device__ __forceinline__ float gelu_erf_s(float y) {
   return y * __builtin_fmaf(yc, p, 0.5f);
 }
 
+// (the attribute means something in the device pass only; the host pass of the same source would warn)
+#ifdef __HIP_DEVICE_COMPILE__
+#define RF_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define RF_NO_PACKED_FP32
+#endif
 // ABL: ablations for tools/bench_encode.py --linear-dbg (experiments build only; results wrong):
 // 1 = every LDS-DMA piece re-reads one cached KiB, 2 = no LDS-DMA in the loop, 4 = no epilogue,
 // 8 = every workgroup stores into one L2-resident window, 16 = no LDS fragment reads, 32 = no MFMAs.
 template <int EPI, int WIDE, int ABL>
-__global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-packed-fp32-ops"))) k_linear_dma(
+__global__ void __launch_bounds__(LD_WAVES * 64, 1) RF_NO_PACKED_FP32 k_linear_dma(
     const _Float16* __restrict__ X, const uint4* __restrict__ Wt, const _Float16* __restrict__ bias,
     _Float16* __restrict__ out, int N, const int32_t* __restrict__ m_ptr, float* __restrict__ dbg) {
   constexpr int KS = HID / 16;   // 24
@@ -588,7 +594,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) __attribute__((target("no-pa
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 31, h = lane >> 5;
+  const int h = lane >> 5;
   const int t0 = blockIdx.x * (WIDE ? 2 * LD_TOK : LD_TOK);
   const int tb = WIDE ? wave : (wave & 3);
   const uint32_t n_ph = (uint32_t)N / 64u;

@@ -65,8 +65,8 @@ def test_encoder_matches_golden_and_oracle(gpu_device, name):
     assert eg < GOLDEN_TOL, eg
 
 
-@pytest.mark.parametrize("B,T,lo", [(1, 7, 7), (1, 1, 1), (1, 20, 20), (1, 32, 32), (1, 33, 33), (3, 256, 1), (70, 33, 1),
-                                    (16, 128, 100)])   # B = 1, T <= 32: the fused QKV + attention launch of a single query
+@pytest.mark.parametrize("B,T,lo", [(1, 7, 7), (1, 1, 1), (1, 20, 20), (1, 32, 32), (1, 33, 33), (5, 24, 1), (3, 256, 1), (70, 33, 1),
+                                    (16, 128, 100)])   # B = 1, T <= 32: the fused QKV + attention launch of a single query; (5, 24): the one-key-block attention
 def test_encoder_ragged_batches(gpu_device, B, T, lo):
     cfg = dict(oenc.MINILM_L6, layers=2, vocab_size=2000)
     rng = np.random.default_rng(B * 1000 + T)

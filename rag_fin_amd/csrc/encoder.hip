@@ -1772,13 +1772,22 @@ __global__ void __launch_bounds__(256) k_pool_norm(const _Float16* __restrict__ 
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    for (int tb = tb0; tb < tb1; ++tb) {
-      const int tok = tb * 32 + t;
-      if (tok >= r0 && tok < r0 + n) {
-        const half8 v = *(const half8*)(x + (((size_t)tb * (HID / 16) + kk) * 64 + lane) * 8);
+    // nine token blocks (a 256-token sequence at any offset) per trip, every load issued before the first add:
+    // one load per trip of a loop with a divergent body was 48 HBM latencies in a row per wave (34 us per batch)
+    for (int tbc = tb0; tbc < tb1; tbc += 9) {
+      half8 v[9];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+      for (int u = 0; u < 9; ++u) {
+        const int tb = tbc + u;
+        const int tok = tb * 32 + t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = (_Float16)0.f;
+        if (tb < tb1 && tok >= r0 && tok < r0 + n) v[u] = *(const half8*)(x + (((size_t)tb * (HID / 16) + kk) * 64 + lane) * 8);
       }
+#pragma unroll
+      for (int u = 0; u < 9; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += (float)v[u][j];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

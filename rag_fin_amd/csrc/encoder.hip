@@ -231,78 +231,81 @@ __global__ void __launch_bounds__(256) k_tok_offsets(const int32_t* __restrict__
   }
 }
 
-// One wave per 32 consecutive positions of one sequence: lane = (position c, feature half h), a loop over the
-// 24 16-feature groups -- the wave's stores are then runs of whole 16-byte slots of the tiled activations (a
-// token's slot of fragment f is next to its neighbour's: 512 contiguous bytes per half, split at most once by a
-// token-block boundary) instead of 48 slots 1 KiB apart per token, and the LayerNorm sums are lane-local plus
-// one xor-32 exchange.  Two sweeps over the embedding rows (statistics, then normalise and store; the second
-// one hits L2): holding a token's 384 fp32 values would take 192 registers per lane.  The per-sequence scalars
-// (length, packed offset) are wave-uniform scalar loads.  Was: one wave per token, four tokens per wave in a
-// row, each a chain of three dependent vector loads -- 49 us per 64 k-token batch.
-// KEEP = 1 (query-sized batches: latency, not throughput): ONE sweep, the 384 sums stay in registers.
-template <int KEEP>
+// One workgroup per 32 consecutive positions of one sequence, lane = (position c, feature half h); its four
+// waves take six of the 24 16-feature groups each.  The wave's stores are runs of whole 16-byte slots of the
+// tiled activations (a token's slot of fragment f is next to its neighbour's: 512 contiguous bytes per half,
+// split at most once by a token-block boundary) instead of 48 slots 1 KiB apart per token; every load of a
+// wave (18 x 16 bytes per lane) is in flight at once and its 48 sums stay in registers; the LayerNorm sums are
+// lane-local plus one xor-32 exchange and one trip through LDS between the four waves.  The per-sequence
+// scalars (length, packed offset) are wave-uniform scalar loads.  (Round-2 history: one wave per token, four
+// tokens per wave in a row, each a chain of three dependent vector loads: 49 us per 64 k-token batch; one wave
+// per 32 positions with two sweeps over the rows: 56 us -- 8 waves per CU cannot hide the latency.)
 __global__ void __launch_bounds__(256) k_embed_ln(
     const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
     const int32_t* __restrict__ tok_off, int B, int T, int vocab, const _Float16* __restrict__ word,
     const _Float16* __restrict__ pos, const _Float16* __restrict__ type, const _Float16* __restrict__ g,
     const _Float16* __restrict__ b, float eps, _Float16* __restrict__ out) {
+  __shared__ float red[2][4][32];
+  constexpr int FW = HID / 16 / 4;                             // feature groups per wave (6)
   const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
   const int cpr = (T + 31) >> 5;                               // 32-position chunks per sequence row
-  const int64_t nchunks = (int64_t)B * cpr;
-  const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t ch = wave0; ch < nchunks; ch += nwaves) {       // wave-uniform
-    const int bi = (int)(ch / cpr), p0 = (int)(ch % cpr) * 32;
-    const int len = min(max(lens[bi], 0), T);
-    if (p0 >= len) continue;
-    const int p = p0 + c;
-    const bool live = p < len;
-    int id = live ? ids[(size_t)bi * T + p] : 0;
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    const _Float16* wrow = word + (size_t)id * HID + 8 * h;
-    const _Float16* prow = pos + (size_t)(live ? p : 0) * HID + 8 * h;
-    const _Float16* trow = type + 8 * h;
-    float s1 = 0.f, s2 = 0.f;
-    float keep[KEEP ? HID / 16 : 1][8];
-#pragma unroll KEEP ? 24 : 6
-    for (int f = 0; f < HID / 16; ++f) {
-      const half8 a = *(const half8*)(wrow + 16 * f);
-      const half8 cc = *(const half8*)(prow + 16 * f);
-      const half8 d = *(const half8*)(trow + 16 * f);
+  const int bi = blockIdx.x / cpr, p0 = (blockIdx.x % cpr) * 32;
+  const int len = min(max(lens[bi], 0), T);
+  if (p0 >= len) return;                                       // workgroup-uniform
+  const int p = p0 + c;
+  const bool live = p < len;
+  int id = live ? ids[(size_t)bi * T + p] : 0;
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const int f0 = 16 * FW * wave + 8 * h;                       // the lane's first feature
+  const _Float16* wrow = word + (size_t)id * HID + f0;
+  const _Float16* prow = pos + (size_t)(live ? p : 0) * HID + f0;
+  const _Float16* trow = type + f0;
+  half8 a[FW], cc[FW], d[FW];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = (float)a[j] + (float)cc[j] + (float)d[j];
-        if (KEEP) keep[f][j] = v;
-        s1 += v;
-        s2 = fmaf(v, v, s2);
-      }
-    }
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
-    const float mu = s1 * (1.f / HID);
-    // E[v^2] - mu^2 in fp32 over 384 values of order 1 with |mu| << 1: the cancellation is ~1e-6 relative
-    const float rstd = rsqrtf(fmaxf(s2 * (1.f / HID) - mu * mu, 0.f) + eps);
-    const int token = tok_off[bi] + p;
-    _Float16* orow = out + ((size_t)(token >> 5) * (HID / 16) * 64 + (size_t)h * 32 + (token & 31)) * 8;
-#pragma unroll KEEP ? 24 : 6
-    for (int f = 0; f < HID / 16; ++f) {
-      half8 a, cc, d;
-      if (!KEEP) {
-        a = *(const half8*)(wrow + 16 * f);
-        cc = *(const half8*)(prow + 16 * f);
-        d = *(const half8*)(trow + 16 * f);
-      }
-      const half8 gg = *(const half8*)(g + 16 * f + 8 * h);
-      const half8 bb = *(const half8*)(b + 16 * f + 8 * h);
-      half8 o;
+  for (int f = 0; f < FW; ++f) {
+    a[f] = *(const half8*)(wrow + 16 * f);
+    cc[f] = *(const half8*)(prow + 16 * f);
+    d[f] = *(const half8*)(trow + 16 * f);
+  }
+  float v[FW][8];
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = KEEP ? keep[f][j] : (float)a[j] + (float)cc[j] + (float)d[j];
-        o[j] = (_Float16)((v - mu) * rstd * (float)gg[j] + (float)bb[j]);
-      }
-      if (live) *(half8*)(orow + (size_t)f * 512) = o;
+  for (int f = 0; f < FW; ++f)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[f][j] = (float)a[f][j] + (float)cc[f][j] + (float)d[f][j];
+      s1 += v[f][j];
+      s2 = fmaf(v[f][j], v[f][j], s2);
     }
+  s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 32);
+  if (h == 0) {
+    red[0][wave][c] = s1;
+    red[1][wave][c] = s2;
+  }
+  // the scale and shift are not needed before the statistics: their round trip sits under the exchange
+  half8 gg[FW], bb[FW];
+#pragma unroll
+  for (int f = 0; f < FW; ++f) {
+    gg[f] = *(const half8*)(g + f0 + 16 * f);
+    bb[f] = *(const half8*)(b + f0 + 16 * f);
+  }
+  __syncthreads();
+  const float t1 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+  const float t2 = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  const float mu = t1 * (1.f / HID);
+  // E[v^2] - mu^2 in fp32 over 384 values of order 1 with |mu| << 1: the cancellation is ~1e-6 relative
+  const float rstd = rsqrtf(fmaxf(t2 * (1.f / HID) - mu * mu, 0.f) + eps);
+  const int token = tok_off[bi] + p;
+  _Float16* orow = out + ((size_t)(token >> 5) * (HID / 16) * 64 + (size_t)h * 32 + (token & 31)) * 8 + (size_t)(FW * wave) * 512;
+#pragma unroll
+  for (int f = 0; f < FW; ++f) {
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)((v[f][j] - mu) * rstd * (float)gg[f][j] + (float)bb[f][j]);
+    if (live) *(half8*)(orow + (size_t)f * 512) = o;
   }
 }
 
@@ -2022,19 +2025,11 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
 
   hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off);
   {
-    int64_t waves = (int64_t)B * ((T + 31) / 32);   // one wave per 32 positions of a row
-    int grid = (int)((waves + 3) / 4);
-    if (grid > 4096) grid = 4096;
-    if (waves <= 64)   // query-sized: one sweep, sums kept in registers
-      hipLaunchKernelGGL(k_embed_ln<1>, dim3(grid), dim3(256), 0, st, ids_dev, lens_dev, ws.tok_off, B, T,
-                         c.vocab_size, (const _Float16*)w.word_emb, (const _Float16*)w.pos_emb,
-                         (const _Float16*)w.type_emb, (const _Float16*)w.emb_ln_g,
-                         (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
-    else
-      hipLaunchKernelGGL(k_embed_ln<0>, dim3(grid), dim3(256), 0, st, ids_dev, lens_dev, ws.tok_off, B, T,
-                         c.vocab_size, (const _Float16*)w.word_emb, (const _Float16*)w.pos_emb,
-                         (const _Float16*)w.type_emb, (const _Float16*)w.emb_ln_g,
-                         (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
+    const int chunks = B * ((T + 31) / 32);   // one workgroup per 32 positions of a row
+    hipLaunchKernelGGL(k_embed_ln, dim3(chunks), dim3(256), 0, st, ids_dev, lens_dev, ws.tok_off, B, T,
+                       c.vocab_size, (const _Float16*)w.word_emb, (const _Float16*)w.pos_emb,
+                       (const _Float16*)w.type_emb, (const _Float16*)w.emb_ln_g,
+                       (const _Float16*)w.emb_ln_b, c.ln_eps, ws.x);
   }
   const size_t attn_lds = (size_t)T * 2 * HEAD_DIM * 2;
   static rf_lds_attr attn_attr;

@@ -1521,8 +1521,11 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
     // l_run, the output accumulator rescaled when the maximum moves).  NHALF = 2 for the long instantiations:
     // the scores of a group, not of the whole sequence, stay in registers -- 64 instead of 128 at T = 256 -- and
     // a fourth workgroup fits the CU's registers (the kernel's time is waiting, not issue: DESIGN.md 4.5).
-    constexpr int HB = KB / NHALF;
-    static_assert(HB * NHALF == KB, "key blocks per group");
+    // The groups are ALWAYS blocks 0-3 and 4-7 -- whatever instantiation a batch's width selects (the second
+    // group of KB = 6 is blocks 4, 5) -- so a sequence's arithmetic does not depend on the batch it is encoded
+    // in: the same text gives the same bits wherever it lands (tests/test_config4_gpu.py).
+    constexpr int HB = NHALF == 1 ? KB : 4;
+    static_assert(NHALF == 1 ? KB <= 4 : (KB > 4 && KB <= 8), "groups of four key blocks");
     const float c2 = scale * 1.4426950408889634f;   // exp(scale * (s - m)) = exp2(c2 * s - c2 * m)
     float m_run = -INFINITY;
     f32x2 l2 = {0.f, 0.f};                          // lane-partial row sum (the two halves of a query's keys meet at the end)
@@ -1544,8 +1547,10 @@ __global__ void __launch_bounds__(256, WPS) k_attention_mfma(const _Float16* __r
       // 1/sqrt(32) scale is folded into the exponent below.
 #pragma unroll
       for (int kk = 0; kk < HB; ++kk) {
-        const int kb = kb0 + kk;
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // (a block past the instantiation's last -- the second group of KB = 6 -- re-reads the last one: its
+        // scores are masked and skipped below like those of any block the sequence does not reach)
+        const int kb = kb0 + kk < KB ? kb0 + kk : KB - 1;
         const half8 a0 = *(const half8*)(ks + (kb * 32 + c) * 40 + 8 * h);
         const half8 a1 = *(const half8*)(ks + (kb * 32 + c) * 40 + 16 + 8 * h);
         sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[0], z, 0, 0, 0);
@@ -1769,26 +1774,27 @@ __global__ void __launch_bounds__(256) k_pool_norm(const _Float16* __restrict__ 
   const int t = lane & 31, h = lane >> 5;
   const int r0 = tok_off[b];
   const int n = tok_off[b + 1] - r0;
-  const int tb0 = r0 >> 5, tb1 = (r0 + n + 31) >> 5;   // token blocks [tb0, tb1)
   const float inv_cnt = 1.f / fmaxf((float)n, 1e-9f);
   for (int kk = wave; kk < HID / 16; kk += 4) {
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    // nine token blocks (a 256-token sequence at any offset) per trip, every load issued before the first add:
-    // one load per trip of a loop with a divergent body was 48 HBM latencies in a row per wave (34 us per batch)
-    for (int tbc = tb0; tbc < tb1; tbc += 9) {
-      half8 v[9];
+    // lane t sums the sequence's tokens t, t + 32, t + 64 ... (SEQUENCE-relative: the order of the additions, and
+    // with it the bits of the result, do not depend on where the sequence sits in the packed stream); eight
+    // tokens per lane and trip, every load issued before the first add -- one load per trip of a loop with a
+    // divergent body was 48 HBM latencies in a row per wave (34 us per batch)
+    for (int i0 = 0; i0 < n; i0 += 256) {
+      half8 v[8];
 #pragma unroll
-      for (int u = 0; u < 9; ++u) {
-        const int tb = tbc + u;
-        const int tok = tb * 32 + t;
+      for (int u = 0; u < 8; ++u) {
+        const int rel = i0 + 32 * u + t;
+        const int tok = r0 + rel;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[u][j] = (_Float16)0.f;
-        if (tb < tb1 && tok >= r0 && tok < r0 + n) v[u] = *(const half8*)(x + (((size_t)tb * (HID / 16) + kk) * 64 + lane) * 8);
+        if (rel < n) v[u] = *(const half8*)(x + (((size_t)(tok >> 5) * (HID / 16) + kk) * 64 + h * 32 + (tok & 31)) * 8);
       }
 #pragma unroll
-      for (int u = 0; u < 9; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] += (float)v[u][j];
     }

@@ -198,6 +198,43 @@ def test_large_batch_edge_lengths_at_any_offset_match_the_oracle(gpu_device, B, 
     assert np.isfinite(got).all()
 
 
+def test_a_sequence_gives_the_same_bits_wherever_it_sits(gpu_device):
+    """Three sequences (37, 150 and 256 tokens) are copied to 60 rows each of a 600-row batch, between random
+    fillers, so that their first tokens fall on every offset of the 32-token tiles of the packed stream: every
+    copy must come out bit-identical (nothing in the forward may depend on a sequence's place -- the tile GEMMs
+    are row-independent, attention and pooling run on sequence-relative indices), and the same rows encoded in
+    batches of other widths (other attention instantiations) must give the same bits again."""
+    import torch
+    from rag_fin_amd.embedder import Embedder
+    cfg = dict(oenc.MINILM_L6, layers=2, vocab_size=3000)
+    emb = Embedder(oenc.random_weights(cfg, 19), cfg, device=gpu_device)
+    rng = np.random.default_rng(5)
+    B, T = 600, 256
+    lens = rng.integers(1, T + 1, B).astype(np.int32)
+    ids = rng.integers(1, 3000, (B, T)).astype(np.int32)
+    base = {0: 37, 1: 150, 2: 256}
+    proto = {k: rng.integers(1, 3000, T).astype(np.int32) for k in base}
+    copies = {k: list(range(10 + k, B, 10))[:60] for k in base}
+    for k, rows in copies.items():
+        for r in rows:
+            ids[r] = proto[k]
+            lens[r] = base[k]
+    out = emb.encode_ids(ids, lens).cpu().numpy().view(np.uint16)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    for k, rows in copies.items():
+        assert len({int(starts[r]) % 32 for r in rows}) >= 16          # many different offsets
+        for r in rows[1:]:
+            assert np.array_equal(out[r], out[rows[0]]), (k, r)
+    # the 37- and the 150-token sequence in narrower batches (other key-block counts; >= 8192 slots: same GEMM path)
+    for k, width in ((0, 64), (0, 128), (1, 192)):
+        Bn = 8192 // width + 8
+        l2 = rng.integers(1, width + 1, Bn).astype(np.int32)
+        i2 = rng.integers(1, 3000, (Bn, width)).astype(np.int32)
+        i2[5], l2[5] = proto[k][:width], base[k]
+        o2 = emb.encode_ids(i2, l2).cpu().numpy().view(np.uint16)
+        assert np.array_equal(o2[5], out[copies[k][0]]), (k, width)
+
+
 def test_large_batch_forward_repeats_bitwise(gpu_device):
     """Short soak of the LDS-DMA GEMMs (k_linear_dma waits on hand-counted vmcnt / lgkmcnt values;
     a misplaced count gives a RARE wrong tile): 40 forwards of a 66 k-slot batch on fresh ids,

@@ -666,13 +666,14 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) RF_NO_PACKED_FP32 k_linear_d
   };
   auto bias_issue = [&](Bias& bq, uint32_t blk) __attribute__((always_inline)) {
     const uint32_t ba = bias_a + blk * 128u;
-    asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(bq.q[0]) : "v"(ba));
-    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(bq.q[1]) : "v"(ba));
-    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(bq.q[2]) : "v"(ba));
-    asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(bq.q[3]) : "v"(ba));
+    // straight into the accumulator half of the register file: the four quads are the block's accumulator input
+    asm volatile("ds_read_b128 %0, %1 offset:0" : "=a"(bq.q[0]) : "v"(ba));
+    asm volatile("ds_read_b128 %0, %1 offset:32" : "=a"(bq.q[1]) : "v"(ba));
+    asm volatile("ds_read_b128 %0, %1 offset:64" : "=a"(bq.q[2]) : "v"(ba));
+    asm volatile("ds_read_b128 %0, %1 offset:96" : "=a"(bq.q[3]) : "v"(ba));
   };
   auto bias_landed = [&](Bias& bq) __attribute__((always_inline)) {   // call after a wait that covers the four reads
-    asm volatile("" : "+v"(bq.q[0]), "+v"(bq.q[1]), "+v"(bq.q[2]), "+v"(bq.q[3]));
+    asm volatile("" : "+a"(bq.q[0]), "+a"(bq.q[1]), "+a"(bq.q[2]), "+a"(bq.q[3]));
   };
   // epilogue of one finished block: acc[4 g + j] = Y[token][32 blk + 8 g + 4 h + j], in four quads.  Four
   // values = four independent dependency chains: a dependent v_fma_f32 issues every ~8 cycles, four
@@ -682,11 +683,13 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) RF_NO_PACKED_FP32 k_linear_d
   // 64 lanes then hold fragment 2 blk + m whole, lane-linear -- two global_store_dwordx4 per block instead of
   // four dwordx2 (the stores are issue-bound per instruction, not per byte).
   _Float16* const out_lane_w = out + (((ABL & 8) ? (size_t)tb : ((size_t)(t0 >> 5) + tb)) * (size_t)(N / 16) * 64 + lane) * 8;
-  auto epi_quad = [&](const f32x16& acc, const Bias& bq, uint32_t blk, int g, uint2& even) __attribute__((always_inline)) {
+  // (the bias is already in: it is the accumulator INPUT of the block's first MFMA -- one VALU operation per
+  // output less in a kernel whose waves are bound by their VALU issue)
+  auto epi_quad = [&](const f32x16& acc, uint32_t blk, int g, uint2& even) __attribute__((always_inline)) {
     if (ABL & 4) return;
     float y[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) y[j] = acc[4 * g + j] + bq.q[g][j];
+    for (int j = 0; j < 4; ++j) y[j] = acc[4 * g + j];
     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) y[j] = gelu_erf_s(y[j]);
@@ -703,10 +706,10 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) RF_NO_PACKED_FP32 k_linear_d
     // nobody reads them -- and a fixed 2 stores per block keeps the vmcnt arithmetic exact.
     *(uint4*)(out_lane_w + ((size_t)((ABL & 8) ? (blk & 1u) : blk) * 2 + (g >> 1)) * 512) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
   };
-  auto epilogue = [&](const f32x16& acc, const Bias& bq, uint32_t blk) __attribute__((always_inline)) {
+  auto epilogue = [&](const f32x16& acc, uint32_t blk) __attribute__((always_inline)) {
     uint2 even;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) epi_quad(acc, bq, blk, g, even);
+    for (int g = 0; g < 4; ++g) epi_quad(acc, blk, g, even);
   };
   // matrix part of a phase: this wave's feature block (par) of the slot x its 32 tokens.  In the WIDE
   // form the epilogue of the PREVIOUS block (prev, blk_prev) is cut into the same instruction stream:
@@ -715,13 +718,14 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) RF_NO_PACKED_FP32 k_linear_d
   // wave and of the other wave of the SIMD) instead of in a VALU-only stretch between two MFMA stretches.
   auto mfma_part = [&](uint32_t ph, const Pieces& nxt, int par, bool with_dma, f32x16& acc, const f32x16* prev,
                        uint32_t blk_prev) __attribute__((always_inline)) {
+    const uint32_t blk_cur = 2u * ph + (uint32_t)par;
     const rf_u32x4* slot = slots + ((ph % LD_SLOTS) * LD_FRAGS + par * KS) * 64 + lane;
     const uint32_t sa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)slot;
     rf_u32x4 fa[2][WL_GRP];
     constexpr int NG = KS / WL_GRP;   // 6
     Bias bq;
     uint2 even;                           // the even quad's packed outputs, waiting for their odd partner
-    if (prev) bias_issue(bq, blk_prev);   // older than every fragment read of this part: covered by its first wait
+    bias_issue(bq, blk_cur);              // older than every fragment read of this part: covered by its first wait
     if (!(ABL & 16)) lds_read_group<0>(fa[0], sa);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
@@ -735,20 +739,22 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) RF_NO_PACKED_FP32 k_linear_d
         } else {
           lds_wait_group<0>(fa[g & 1]);
         }
-        if (prev && g == 0) bias_landed(bq);
+        if (g == 0) bias_landed(bq);
         if (with_dma && g < LD_PW && !(ABL & 2)) issue_piece(nxt, g);   // one LDS-DMA piece per group of 4 MFMAs
       }
       const half8 a = __builtin_bit_cast(half8, fa[g & 1][j]);
       if (ABL & 32) {   // no MFMAs
         if (kk == 0) asm volatile("" : "=v"(acc));
       } else if (kk == 0) {
-        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), z, 0, 0, 0);
+        // accumulator input = the block's bias in the accumulator's layout (register 4 q + j = feature 8 q + 4 h + j)
+        const f32x16 b0 = {bq.q[0][0], bq.q[0][1], bq.q[0][2], bq.q[0][3], bq.q[1][0], bq.q[1][1], bq.q[1][2], bq.q[1][3],
+                           bq.q[2][0], bq.q[2][1], bq.q[2][2], bq.q[2][3], bq.q[3][0], bq.q[3][1], bq.q[3][2], bq.q[3][3]};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), b0, 0, 0, 0);
       } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(half8, xf[kk]), acc, 0, 0, 0);
       }
       if (prev && kk % 6 == 5) {
-        epi_quad(*prev, bq, blk_prev, kk / 6, even);
+        epi_quad(*prev, blk_prev, kk / 6, even);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -772,13 +778,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) RF_NO_PACKED_FP32 k_linear_d
       mfma_part(ph, nxt, 0, true, acc0, &acc1, ph ? 2u * ph - 1u : 0u);
       mfma_part(ph, nxt, 1, false, acc1, &acc0, 2u * ph);
     }
-    {   // the last block's epilogue has no MFMAs to hide under
-      Bias bq;
-      bias_issue(bq, nblk - 1u);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      bias_landed(bq);
-      epilogue(acc1, bq, nblk - 1u);
-    }
+    epilogue(acc1, nblk - 1u);   // the last block's epilogue has no MFMAs to hide under
   } else {
     f32x16 acc;
     for (uint32_t ph = 0; ph < n_ph; ++ph) {
@@ -794,11 +794,7 @@ __global__ void __launch_bounds__(LD_WAVES * 64, 1) RF_NO_PACKED_FP32 k_linear_d
       // than six issues spread over the MFMA groups.
       const int par = wave >> 2;
       mfma_part(ph, nxt, par, true, acc, nullptr, 0u);
-      Bias bq;
-      bias_issue(bq, 2u * ph + (uint32_t)par);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      bias_landed(bq);
-      epilogue(acc, bq, 2u * ph + (uint32_t)par);
+      epilogue(acc, 2u * ph + (uint32_t)par);
     }
   }
   if (ABL & 4) asm volatile("" ::"v"(out_lane_w));

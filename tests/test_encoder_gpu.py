@@ -101,6 +101,11 @@ def test_zero_length_row_gives_zero_vector(gpu_device):
     emb = Embedder(oenc.random_weights(cfg, 1), cfg, device=gpu_device)
     out = emb.encode_ids(np.ones((2, 4), np.int32), np.array([0, 3], np.int32)).float().cpu().numpy()
     assert np.all(out[0] == 0) and abs(np.linalg.norm(out[1]) - 1) < 1e-3
+    # a single empty sequence (the one-launch QKV + attention path of a lone query): zeros, nothing else
+    one = emb.encode_ids(np.ones((1, 4), np.int32), np.array([0], np.int32)).float().cpu().numpy()
+    assert one.shape == (1, 384) and np.all(one == 0)
+    again = emb.encode_ids(np.ones((1, 4), np.int32), np.array([3], np.int32)).float().cpu().numpy()
+    assert np.array_equal(again[0], out[1])      # and the path is clean afterwards
 
 
 def test_unsupported_config_fails_loudly(gpu_device):

@@ -28,7 +28,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libragfin_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
 EXP_LIB_PATH = os.path.join(CSRC, "libragfin_hip_exp.so")
-SOURCES = ["index.hip", "scan.hip", "scan_wide.hip", "merge.hip", "api.hip", "encoder.hip", "tokenizer.cpp"]
+SOURCES = ["index.hip", "scan.hip", "scan_wide.hip", "merge.hip", "api.hip", "encoder.hip", "encoder_post.hip", "tokenizer.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -28,30 +28,11 @@
 //                   kept for longer sequences
 //   k_qkv_attn_one  a single sequence of <= 32 tokens: K2 + K3 of a head in one launch
 //   k_pool_norm     mean over the sequence, L2-normalise                      (K7)
-#include "rf_internal.h"
-#include "lds_ring.h"
+#include "encoder_internal.h"
 #include <mutex>
 #include <new>
 #include <stdlib.h>
 #include <vector>
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define HID 384
-#define HEAD_DIM 32
-
-// Activations live in the same fragment tiling as the corpus and the weights:
-// [token block of 32][k-step = feature/16][lane = 32*((feature/8)&1) + token%32][8 halfs].
-// A 32-token x 16-feature fragment is 1 KiB contiguous, so the GEMMs read their B
-// operands with one coalesced wave load, and an epilogue's 4-consecutive-feature
-// stores of a wave fill 512 contiguous bytes.  (Row-major activations made every
-// B-fragment load touch 32 different cache lines: the GEMMs were TA-bound at ~17 %
-// of the matrix peak.)  toff() = offset in halfs of (token t, feature f); KSf = width/16.
-__device__ __forceinline__ size_t toff(int t, int f, int KSf) {
-  return (((size_t)(t >> 5) * KSf + (f >> 4)) * 64 + (size_t)(((f >> 3) & 1) * 32 + (t & 31))) * 8 + (f & 7);
-}
 
 struct rf_encoder {
   rf_encoder_config cfg;
@@ -61,6 +42,7 @@ struct rf_encoder {
   const uint4* ao_t;         // tiled [L][H/32][H/16][64]
   const uint4* ff1_t;        // tiled [L][I/32][H/16][64]
   const uint4* ff2_t;        // tiled [L][H/32][I/16][64]
+  const uint4* post_t;       // per-layer packs of k_post_block [L][PB_PACK_FRAGS][64] (encoder_post.hip)
   // small batches: the ~45 launches of a forward as ONE hipGraph per (shape, buffers) -- a
   // 12-token query is launch-bound (5 us of host time per launch against 2-5 us of kernel)
   struct Graph {
@@ -88,7 +70,7 @@ static size_t layer_weight_elems(const rf_encoder_config* c) {
 
 extern "C" size_t rf_encoder_storage_bytes(const rf_encoder_config* cfg) {
   if (!cfg_supported(cfg)) return 0;
-  return (size_t)cfg->layers * layer_weight_elems(cfg) * sizeof(_Float16);
+  return (size_t)cfg->layers * (layer_weight_elems(cfg) + rf_post_pack_elems()) * sizeof(_Float16);
 }
 
 extern "C" int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cfg,
@@ -132,16 +114,19 @@ extern "C" int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cf
   _Float16* ao = qkv + (size_t)L * 3 * HID * HID;
   _Float16* ff1 = ao + (size_t)L * HID * HID;
   _Float16* ff2 = ff1 + (size_t)L * I * HID;
+  _Float16* post = ff2 + (size_t)L * HID * I;
   // [L*out, in] row-major -> tiled; out is a multiple of 32 so layers tile independently
   rf_launch_tile_rows(w->qkv_w, (uint4*)qkv, 0, (int64_t)L * 3 * HID, HID / 16, st);
   rf_launch_tile_rows(w->ao_w, (uint4*)ao, 0, (int64_t)L * HID, HID / 16, st);
   rf_launch_tile_rows(w->ff1_w, (uint4*)ff1, 0, (int64_t)L * I, HID / 16, st);
   rf_launch_tile_rows(w->ff2_w, (uint4*)ff2, 0, (int64_t)L * HID, I / 16, st);
+  rf_launch_post_pack_build(w, post, L, st);
   RF_HIP(hipGetLastError());
   e->qkv_t = (const uint4*)qkv;
   e->ao_t = (const uint4*)ao;
   e->ff1_t = (const uint4*)ff1;
   e->ff2_t = (const uint4*)ff2;
+  e->post_t = (const uint4*)post;
   *out = e;
   return RF_OK;
 }
@@ -572,12 +557,6 @@ __device__ __forceinline__ float gelu_erf_s(float y) {
   return y * __builtin_fmaf(yc, p, 0.5f);
 }
 
-// (the attribute means something in the device pass only; the host pass of the same source would warn)
-#ifdef __HIP_DEVICE_COMPILE__
-#define RF_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
-#else
-#define RF_NO_PACKED_FP32
-#endif
 // ABL: ablations for tools/bench_encode.py --linear-dbg (experiments build only; results wrong):
 // 1 = every LDS-DMA piece re-reads one cached KiB, 2 = no LDS-DMA in the loop, 4 = no epilogue,
 // 8 = every workgroup stores into one L2-resident window, 16 = no LDS fragment reads, 32 = no MFMAs.
@@ -2099,6 +2078,24 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
     else
       hipLaunchKernelGGL(k_attention, dim3(B, c.heads), dim3(256), attn_lds, st, ws.qkv, ws.tok_off,
                          ws.ctx);
+    }
+    if (rf_knob_post_block && tiles >= 8192) {
+      // out-projection + LayerNorm, FFN1 + GELU, FFN2 + LayerNorm in one launch (encoder_post.hip): x -> y
+      rf_post_args pa;
+      pa.ctx = ws.ctx;
+      pa.res = x;
+      pa.out = y;
+      pa.pack = enc->post_t + (size_t)l * rf_post_pack_elems() / 8;
+      pa.eps = c.ln_eps;
+      pa.m_ptr = m_ptr;
+      pa.dbg = (rf_knob_debug_epi == 5) ? (float*)rf_debug_buffer : nullptr;
+      pa.abl = rf_knob_post_dbg;
+      const int prc = rf_launch_post_block(pa, tiles, st);
+      if (prc != RF_OK) return prc;
+      _Float16* t_ = x;
+      x = y;
+      y = t_;
+      continue;
     }
     launch_linear<EPI_BIAS_RES_LN>(ws.ctx, HID, ao_t, (const _Float16*)w.ao_b + (size_t)l * HID, y, HID,
                                    tiles, m_ptr, x, (const _Float16*)w.ln1_g + (size_t)l * HID,

@@ -1,0 +1,566 @@
+// The post-attention half of an encoder layer in ONE launch (round 3):
+//
+//   y  = LayerNorm(ctx Wo^T + bo + x)                       out-projection (K4)
+//   h  = GELU(y W1^T + b1)                                   FFN1 (K5)
+//   x' = LayerNorm(h W2^T + b2 + y)                          FFN2 (K6)
+//
+// (BertSelfOutput, BertIntermediate, BertOutput of the model behind SentenceTransformer.encode:
+// vector_rag_mcp/main.py:50, "chunking_storing (1).py":379-380.)  As three launches the 64 k-token
+// batch wrote y (50 MB) and h (201 MB) to HBM and read them back (0.68 GB of the layer's 1.12 GB
+// were such round trips), paid three prologues / drains and two LayerNorm exchanges through LDS.
+//
+// Here a WAVE owns 32 tokens x ALL features, one wave per SIMD (4 waves = 128 tokens per
+// workgroup, up to 512 registers per lane):
+//   * every GEMM is  acc^T[feature][token] += W-fragment (A, from LDS) x activation-fragment (B,
+//     registers): the 32x32 accumulator holds the TOKEN on the lane and 16 features in registers --
+//     registers 8 s .. 8 s + 7 of lane (c, h) are the features 32 b + 8 (2 s + (e >> 2)) + 4 h + (e & 3);
+//   * converted to fp16 these eight registers ARE a B operand of the next GEMM for a k-step whose
+//     sixteen k indices are that permutation of the block's features.  A dot product does not care
+//     in which order k runs as long as both operands agree, so the weights of the consuming GEMM are
+//     stored once with their k axis permuted the same way (rf_launch_post_stream_build):  y feeds
+//     FFN1 and h feeds FFN2 register to register, no LDS exchange, no transposition;
+//   * a token's 384 features sit in lanes c and c + 32 of one wave: the LayerNorm statistics are
+//     lane-local sums plus one xor-32 exchange -- no LDS, no barrier;
+//   * the weights (Wo: 288 KiB, W1 + W2: 2.25 MiB per layer, L2-resident) stream through a 3-slot
+//     LDS ring by LDS-DMA, 48 KiB per step, two steps ahead behind a counted vmcnt and one raw
+//     s_barrier per step; all four waves read every fragment (one ds_read_b128 per MFMA).
+//   * MLP step i = { FFN2 of block i - 2 (24 MFMAs), FFN1 of block i (24 MFMAs) } with the GELU of
+//     block i - 1 cut into the 48 MFMA gaps (5.3 plain VALU operations per gap): the slot of step i
+//     holds W1[block i] and the W2 columns of block i - 2.
+// Registers: acc2 192 + activations 96 + two FFN1 accumulators 32 + two h operands 16 + LDS read
+// groups 32 + GELU temporaries ~16.
+#include "encoder_internal.h"
+#include <type_traits>
+
+#define PB_TOK 128
+#define PB_WAVES 4
+#define PB_SLOTS 3
+#define PB_PW (PB_FRAGS / PB_WAVES)   // LDS-DMA pieces per wave and step (12)
+#define PB_STEPS (PB_STEPS_A + PB_STEPS_B)
+#define PB_PARAM_FLOATS (4 * HID + 6 * HID)   // b1, then bo, g1, be1, b2, g2, be2
+#define PB_LDS_BYTES ((size_t)PB_SLOTS * PB_FRAGS * 1024 + (size_t)PB_PARAM_FRAGS * 1024)
+
+// ---- the per-layer pack ---------------------------------------------------------------------------
+// pack[l][fragment F][lane][16 bytes]:
+//   F < 16:         parameters as fp32: b1 [1536], bo, g1, be1, b2, g2, be2 [384 each] (15 KiB), then zeros
+//   16 <= F < 304:  out-projection weights, standard fragment tiling [block 0..11][k-step 0..23]
+//   304 <= F:       the MLP stream [step i 0..49][fragment f 0..47], lane = 32 h + r:
+//     f < 24  (i < 48):  W1[32 i + r][perm(f, h, e)]                          FFN1 block i, k-step f
+//     f >= 24 (i >= 2):  W2[32 ob + r][32 (i - 2) + perm(s, h, e)], ob = (f - 24) >> 1, s = (f - 24) & 1
+//   perm(q, h, e) = 32 (q >> 1) + 16 (q & 1) + 8 (e >> 2) + 4 h + (e & 3): the feature that register
+//   8 (q & 1) + e of a 32x32 accumulator of block q >> 1 holds in lane half h.  Unused fragments are zero.
+struct PackSrc {
+  const _Float16 *ao_w, *ff1_w, *ff2_w, *ff1_b, *ao_b, *ln1_g, *ln1_b, *ff2_b, *ln2_g, *ln2_b;
+};
+__global__ void __launch_bounds__(256) k_post_pack_build(const PackSrc w, uint4* __restrict__ pack, int L) {
+  constexpr int I = 4 * HID;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)L * PB_PACK_FRAGS * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const int F = (int)((idx >> 6) % PB_PACK_FRAGS);
+  const int l = (int)(idx / ((size_t)64 * PB_PACK_FRAGS));
+  const int r = lane & 31, h = lane >> 5;
+  if (F < 16) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int j = (F * 64 + lane) * 4;   // first of the lane's four floats
+    if (j < I) {
+      const _Float16* p = w.ff1_b + (size_t)l * I + j;
+      o = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+    } else if (j < PB_PARAM_FLOATS) {
+      const int v = (j - I) / HID, k = (j - I) % HID;
+      const _Float16* base = v == 0 ? w.ao_b : v == 1 ? w.ln1_g : v == 2 ? w.ln1_b : v == 3 ? w.ff2_b : v == 4 ? w.ln2_g : w.ln2_b;
+      const _Float16* p = base + (size_t)l * HID + k;
+      o = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+    }
+    pack[idx] = __builtin_bit_cast(uint4, o);
+    return;
+  }
+  half8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.f;
+  if (F < 16 + PB_STEPS_A * PB_FRAGS) {
+    const int b = (F - 16) / 24, kk = (F - 16) % 24;
+    const _Float16* src = w.ao_w + ((size_t)l * HID + 32 * b + r) * HID + 16 * kk + 8 * h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = src[e];
+  } else {
+    const int i = (F - 16 - PB_STEPS_A * PB_FRAGS) / PB_FRAGS, f = (F - 16 - PB_STEPS_A * PB_FRAGS) % PB_FRAGS;
+    const _Float16* src = nullptr;
+    if (f < 24) {
+      if (i < 48) src = w.ff1_w + ((size_t)l * I + 32 * i + r) * HID + 32 * (f >> 1) + 16 * (f & 1) + 4 * h;
+    } else if (i >= 2) {
+      const int m = f - 24;
+      src = w.ff2_w + ((size_t)l * HID + 32 * (m >> 1) + r) * I + 32 * (i - 2) + 16 * (m & 1) + 4 * h;
+    }
+    if (src) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = src[e];
+        o[4 + e] = src[8 + e];
+      }
+    }
+  }
+  pack[idx] = __builtin_bit_cast(uint4, o);
+}
+
+void rf_launch_post_pack_build(const rf_encoder_weights* w, void* pack, int L, hipStream_t st) {
+  const size_t total = (size_t)L * PB_PACK_FRAGS * 64;
+  PackSrc ps;
+  ps.ao_w = (const _Float16*)w->ao_w;
+  ps.ff1_w = (const _Float16*)w->ff1_w;
+  ps.ff2_w = (const _Float16*)w->ff2_w;
+  ps.ff1_b = (const _Float16*)w->ff1_b;
+  ps.ao_b = (const _Float16*)w->ao_b;
+  ps.ln1_g = (const _Float16*)w->ln1_g;
+  ps.ln1_b = (const _Float16*)w->ln1_b;
+  ps.ff2_b = (const _Float16*)w->ff2_b;
+  ps.ln2_g = (const _Float16*)w->ln2_g;
+  ps.ln2_b = (const _Float16*)w->ln2_b;
+  hipLaunchKernelGGL(k_post_pack_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ps, (uint4*)pack, L);
+}
+
+// ---- compile-time loops ---------------------------------------------------------------------------
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// ---- GELU of one FFN1 block (16 values per lane), cut into 256 slots ------------------------------
+// The arithmetic of gelu_erf_s (encoder.hip): h(y) = y (1/2 + yc Q(t)), yc = y clamped to +-3.2 sqrt 2,
+// t = yc^2 / 3.2^2 - 1, Q the degree-10 erf polynomial with 1 / (2 sqrt 2) folded in; plain fp32 only
+// (packed fp32 does not issue under MFMAs).  Slot O: quad O >> 6 (accumulator registers 4 q .. 4 q + 3,
+// four independent dependency chains), within it 15 stages x 4 values, then two fp16 pair conversions.
+struct GeluTmp {
+  float yc[4], t[4], p[4];
+};
+__device__ constexpr float kGeluK[11] = {8.469007444e-04f, -2.387454268e-03f, 3.280109027e-03f, -5.588355009e-03f,
+                                         1.136882324e-02f, -1.921003498e-02f, 2.861942165e-02f, -4.021260887e-02f,
+                                         5.456056446e-02f, -7.682786137e-02f, 1.560353935e-01f};
+template <int O>
+__device__ __forceinline__ void gelu_slot(const f32x16& y, GeluTmp& g, uint32_t (&hw)[8]) {
+  constexpr int quad = O >> 6, w = O & 63;
+  if constexpr (w < 60) {
+    constexpr int st = w >> 2, v = w & 3;
+    const float yv = y[4 * quad + v];
+    if constexpr (st == 0) {
+      constexpr float CP = 4.52548360824585f;   // 3.2 sqrt 2
+      g.yc[v] = __builtin_amdgcn_fmed3f(yv, -CP, CP);
+    } else if constexpr (st == 1) {
+      g.t[v] = g.yc[v] * g.yc[v];
+    } else if constexpr (st == 2) {
+      g.t[v] = __builtin_fmaf(g.t[v], 0.09765625f, -1.f);
+    } else if constexpr (st == 3) {
+      g.p[v] = __builtin_fmaf(g.t[v], kGeluK[0], kGeluK[1]);
+    } else if constexpr (st <= 12) {
+      g.p[v] = __builtin_fmaf(g.t[v], g.p[v], kGeluK[st - 2]);
+    } else if constexpr (st == 13) {
+      g.p[v] = __builtin_fmaf(g.yc[v], g.p[v], 0.5f);
+    } else {
+      g.p[v] = yv * g.p[v];
+    }
+  } else if constexpr (w < 62) {
+    constexpr int pr = w - 60;
+    const half2v o = {(_Float16)g.p[2 * pr], (_Float16)g.p[2 * pr + 1]};
+    hw[2 * quad + pr] = __builtin_bit_cast(uint32_t, o);
+  }
+}
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// DBG: clock stamps per wave into a.dbg.  ABL (experiments build; results wrong): 1 = no LDS-DMA in the MLP
+// steps, 2 = no GELU, 4 = no LDS fragment reads in the MLP steps, 8 = no MFMAs in the MLP steps.
+template <int DBG, int ABL>
+__global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_block(const rf_post_args a) {
+  constexpr int KS = HID / 16;   // 24
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  rf_u32x4* const slots = (rf_u32x4*)smem_raw;                           // [3][48 * 64]
+  float* const b1_l = (float*)(slots + PB_SLOTS * PB_FRAGS * 64);        // parameter block: FFN1 bias [1536] ...
+  const float* const pvf = b1_l + 4 * HID;                               // ... bo, g1, be1, b2, g2, be2 [6][384]
+  const uint64_t ts_entry = DBG ? __builtin_amdgcn_s_memtime() : 0;
+  const uint64_t tr_entry = DBG ? __builtin_amdgcn_s_memrealtime() : 0;
+  uint64_t ts_a = 0, ts_ln1 = 0, ts_b = 0, ts_ln2 = 0, t_wait = 0;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, h = lane >> 5;
+  const int t0 = blockIdx.x * PB_TOK;
+  const size_t tb = (size_t)(t0 >> 5) + wave;   // this wave's token block
+
+  // Ring step S (0..5: two out-projection feature blocks; 6 + i: step i of the MLP stream) = 48 contiguous
+  // fragments of the pack; piece p of wave w = fragment 12 w + p.  The source is a wave-uniform pointer
+  // (scalar registers) + the lane's 16 bytes.  Pieces past the last step are issued all the same (the counted
+  // waits assume 12 per step): they re-read step 0 into a slot nobody reads any more.
+  const char* const ring_src = (const char*)a.pack + ((size_t)16 + (size_t)wave * PB_PW) * 1024;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  // (inline asm: hipcc's builtin took the source as a per-lane 64-bit address -- one v_lshl_add_u64 per piece in
+  // a kernel bound by its VALU issue -- and every compiler-visible LDS read after it drew an s_waitcnt vmcnt(0).
+  // All LDS-DMA of this kernel is asm, so the compiler never holds anything in M0 across these statements.)
+  auto issue_piece = [&](const char* src_step, uint32_t dst_step, int p) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(dst_step + (uint32_t)p * 1024u), "v"(lane_off), "s"(src_step + (size_t)p * 1024) : "memory");
+  };
+  auto step_src = [&](int S) __attribute__((always_inline)) {
+    return ring_src + (size_t)(S < PB_STEPS ? S : 0) * (PB_FRAGS * 1024);
+  };
+  const uint32_t slots_s = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)slots;   // LDS byte address
+  auto step_dst = [&](int S) __attribute__((always_inline)) {
+    return slots_s + (uint32_t)(((S % PB_SLOTS) * PB_FRAGS + wave * PB_PW) * 1024);
+  };
+
+  // Prologue in dependency order: the wave's attention output (first MFMA), the parameter block and the first
+  // two ring steps, then the token count (every read above is legal for any workgroup: buffers are padded).
+  rf_u32x4 xf[KS];   // B-operand fragments: first ctx, then y
+  {
+    const _Float16* src = a.ctx + (tb * KS * 64 + lane) * 8;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) xf[kk] = *(const rf_u32x4*)(src + (size_t)kk * 512);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = wave + 4 * q;   // parameter fragment (15 of them)
+    if (f < PB_PARAM_FRAGS)
+      issue_piece((const char*)a.pack + (size_t)f * 1024, slots_s + (uint32_t)((PB_SLOTS * PB_FRAGS + f) * 1024), 0);
+  }
+#pragma unroll
+  for (int p = 0; p < PB_PW; ++p) issue_piece(step_src(0), step_dst(0), p);
+#pragma unroll
+  for (int p = 0; p < PB_PW; ++p) issue_piece(step_src(1), step_dst(1), p);
+  const int M = *a.m_ptr;
+  if (t0 >= M) {   // whole workgroup; its LDS-DMA pieces must land before the LDS is handed on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my parameter pieces (and the first ring pieces: needed at once anyway)
+  __syncthreads();   // parameters in LDS
+
+  // lane's features of a 32-feature block b: 32 b + 8 g + 4 h + j  (register 4 g + j)
+  auto param4 = [&](int which, int b, int g) __attribute__((always_inline)) {
+    return *(const f32x4v*)(pvf + which * HID + 32 * b + 8 * g + 4 * h);
+  };
+  auto load_vec = [&](int which, f32x16 (&dst)[12]) __attribute__((always_inline)) {
+    static_for<0, 12>([&](auto Bc) __attribute__((always_inline)) {
+      constexpr int b = decltype(Bc)::value;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4v v = param4(which, b, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[b][4 * g + j] = v[j];
+      }
+    });
+  };
+  const uint32_t slots_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)slots + lane_off;
+  auto sync_step = [&]() __attribute__((always_inline)) {
+    uint64_t ts0 = 0;
+    if (DBG) ts0 = __builtin_amdgcn_s_memtime();
+    // my pieces of this step have landed (those of the next step, 12, may stay in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB_PW) : "memory");
+    // ... after the barrier everybody's have, and everybody has read the previous step (its slot is free)
+    __builtin_amdgcn_s_barrier();
+    if (DBG) t_wait += __builtin_amdgcn_s_memtime() - ts0;
+  };
+  // The residual of a LayerNorm is added on the matrix pipe: acc += I x^T with an identity fragment as the A
+  // operand -- exact (1.0 x value, fp32 accumulate), and the residual arrives as the B-operand fragments it is
+  // stored as: no half exchange between lanes, no conversions, no adds (24 MFMAs instead of ~430 VALU operations
+  // in a kernel whose waves are bound by their VALU issue).  std: k = 16 s + 8 h + e (the tiled activations);
+  // perm: k = 16 s + 8 (e >> 2) + 4 h + (e & 3) (y as the accumulator left it).
+  half8 id_std[2], id_perm[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      id_std[s][e] = (r32 == 16 * s + 8 * h + e) ? (_Float16)1.f : (_Float16)0.f;
+      id_perm[s][e] = (r32 == 16 * s + 8 * (e >> 2) + 4 * h + (e & 3)) ? (_Float16)1.f : (_Float16)0.f;
+    }
+
+  // ---- phase A: out-projection ------------------------------------------------------------------------
+  f32x16 acc[12];   // [feature block]: acc_o, later acc2
+  load_vec(0, acc);  // accumulator input = bias
+  rf_u32x4 xr[KS];   // the layer input (residual), fetched under the last two steps
+  if (DBG) ts_a = __builtin_amdgcn_s_memtime();
+  static_for<0, PB_STEPS_A>([&](auto Sc) __attribute__((always_inline)) {
+    constexpr int S = decltype(Sc)::value;
+    sync_step();
+    if constexpr (S == PB_STEPS_A - 2) {   // older than this step's pieces: the counted waits only over-wait
+      const _Float16* rsrc = a.res + (tb * KS * 64 + lane) * 8;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) xr[kk] = *(const rf_u32x4*)(rsrc + (size_t)kk * 512);
+    }
+    const uint32_t sa = slots_a + (uint32_t)((S % PB_SLOTS) * PB_FRAGS * 1024);
+    const char* const nsrc = step_src(S + 2);
+    const uint32_t ndst = step_dst(S + 2);
+    rf_u32x4 fa[2][WL_GRP];
+    // MFMA m of the step: feature block 2 S + (m & 1), k-step m >> 1 -- the two blocks' accumulation chains alternate
+    auto read_group = [&](auto Gc, rf_u32x4 (&d)[WL_GRP]) __attribute__((always_inline)) {
+      constexpr int G = decltype(Gc)::value;
+      lds_read_frag<2 * G>(d[0], sa);
+      lds_read_frag<24 + 2 * G>(d[1], sa);
+      lds_read_frag<2 * G + 1>(d[2], sa);
+      lds_read_frag<24 + 2 * G + 1>(d[3], sa);
+    };
+    read_group(std::integral_constant<int, 0>{}, fa[0]);
+    static_for<0, PB_FRAGS / WL_GRP>([&](auto Gc) __attribute__((always_inline)) {
+      constexpr int G = decltype(Gc)::value;
+      if constexpr (G + 1 < PB_FRAGS / WL_GRP) {
+        read_group(std::integral_constant<int, G + 1>{}, fa[(G + 1) & 1]);
+        lds_wait_group<WL_GRP>(fa[G & 1]);
+      } else {
+        lds_wait_group<0>(fa[G & 1]);
+      }
+      static_for<0, WL_GRP>([&](auto Jc) __attribute__((always_inline)) {
+        constexpr int J = decltype(Jc)::value;
+        constexpr int m = G * WL_GRP + J, fb = 2 * S + (m & 1), kk = m >> 1;
+        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[G & 1][J]),
+                                                         __builtin_bit_cast(half8, xf[kk]), acc[fb], 0, 0, 0);
+      });
+      issue_piece(nsrc, ndst, G);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
+  static_for<0, KS>([&](auto Kc) __attribute__((always_inline)) {   // + x
+    constexpr int kk = decltype(Kc)::value;
+    acc[kk >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id_std[kk & 1], __builtin_bit_cast(half8, xr[kk]), acc[kk >> 1], 0, 0, 0);
+  });
+  if (DBG) {
+    asm volatile("" : "+v"(acc[11]));
+    ts_ln1 = __builtin_amdgcn_s_memtime();
+  }
+
+  // ---- LayerNorm 1 over v = acc; y -> fp16 -> the B operands of FFN1 ---------------------------------
+  const float inv_h = 1.f / HID;
+  auto ln_stats = [&](float& sc, float& sh) __attribute__((always_inline)) {
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // four chains each
+    static_for<0, 12>([&](auto Fc) __attribute__((always_inline)) {
+      constexpr int fb = decltype(Fc)::value;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s1[i & 3] += acc[fb][i];
+        s2[i & 3] = fmaf(acc[fb][i], acc[fb][i], s2[i & 3]);
+      }
+    });
+    float t1 = (s1[0] + s1[1]) + (s1[2] + s1[3]), t2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    t1 += __shfl_xor(t1, 32);
+    t2 += __shfl_xor(t2, 32);
+    const float mu = t1 * inv_h;
+    // E[v^2] - mu^2 in fp32: residual-stream values of order 1 with |mu| << spread (as k_gemm_tile)
+    sc = rsqrtf(fmaxf(t2 * inv_h - mu * mu, 0.f) + a.eps);
+    sh = -mu * sc;
+  };
+  {
+    float sc, sh;
+    ln_stats(sc, sh);
+    static_for<0, 12>([&](auto Fc) __attribute__((always_inline)) {
+      constexpr int fb = decltype(Fc)::value;
+      uint32_t w[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4v gv = param4(1, fb, g), be = param4(2, fb, g);
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = fmaf(fmaf(acc[fb][4 * g + j], sc, sh), gv[j], be[j]);
+        const half2v lo = {(_Float16)y[0], (_Float16)y[1]}, hi = {(_Float16)y[2], (_Float16)y[3]};
+        w[2 * g] = __builtin_bit_cast(uint32_t, lo);
+        w[2 * g + 1] = __builtin_bit_cast(uint32_t, hi);
+      }
+      rf_u32x4 f0 = {w[0], w[1], w[2], w[3]}, f1 = {w[4], w[5], w[6], w[7]};
+      xf[2 * fb] = f0;
+      xf[2 * fb + 1] = f1;
+    });
+  }
+  load_vec(3, acc);   // acc2: accumulator input = FFN2 bias
+  if (DBG) {
+    asm volatile("" : "+v"(acc[11]));
+    ts_b = __builtin_amdgcn_s_memtime();
+  }
+
+  // ---- phase B: the MLP -------------------------------------------------------------------------------
+  f32x16 acc1[2];
+  uint32_t hw[2][8];   // h of a block as two B operands (k-steps): words 4 s .. 4 s + 3
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hw[0][i] = hw[1][i] = 0u;
+  GeluTmp gt;
+  const uint32_t bias_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)b1_l + (uint32_t)h * 16u;
+  // step i: FFN2 of block i - 2 (F2), FFN1 of block i (F1), GELU of block i - 1 (GE); PAR = i & 1
+  auto mlp_step = [&](auto f2c, auto f1c, auto gec, auto parc, int i) __attribute__((always_inline)) {
+    constexpr bool F2 = decltype(f2c)::value, F1 = decltype(f1c)::value, GE = decltype(gec)::value && !(ABL & 2);
+    constexpr int PAR = decltype(parc)::value;
+    constexpr int NG = (F2 ? 6 : 0) + (F1 ? 6 : 0);      // LDS read groups = groups of 4 MFMAs
+    constexpr int NM = NG * WL_GRP;                       // MFMA gaps of the step
+    const int S = PB_STEPS_A + i;
+    sync_step();
+    const uint32_t sa = slots_a + (uint32_t)((S % PB_SLOTS) * PB_FRAGS * 1024);
+    const char* const nsrc = step_src(S + 2);
+    const uint32_t ndst = step_dst(S + 2);
+    f32x4v bq[4];
+    if constexpr (F1) {   // FFN1 bias of block i: the accumulator input; older than every fragment read of the step
+      const uint32_t ba = bias_a + (uint32_t)i * 128u;
+      asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(bq[0]) : "v"(ba));
+      asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(bq[1]) : "v"(ba));
+      asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(bq[2]) : "v"(ba));
+      asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(bq[3]) : "v"(ba));
+    }
+    rf_u32x4 fa[2][WL_GRP];
+    // MFMA gap n of the step -> its A fragment.  In a full step the two GEMMs ALTERNATE (n even: FFN2 number n / 2,
+    // n odd: FFN1 k-step n / 2): FFN1 is one chain of 24 dependent MFMAs on a vector-register accumulator and a
+    // dependent MFMA of that form issues ~10 cycles late (stamps: 2 020 against 1 786 cycles per step with the
+    // chain back to back) -- with an independent FFN2 product between two links the chain never waits.
+    auto frag_of = [](int n) constexpr { return (F2 && F1) ? ((n & 1) ? (n >> 1) : 24 + (n >> 1)) : (F2 ? 24 + n : n); };
+    auto read_group = [&](auto Gc, rf_u32x4 (&d)[WL_GRP]) __attribute__((always_inline)) {
+      constexpr int G = decltype(Gc)::value;
+      lds_read_frag<frag_of(4 * G + 0)>(d[0], sa);
+      lds_read_frag<frag_of(4 * G + 1)>(d[1], sa);
+      lds_read_frag<frag_of(4 * G + 2)>(d[2], sa);
+      lds_read_frag<frag_of(4 * G + 3)>(d[3], sa);
+    };
+    if constexpr (!(ABL & 4)) read_group(std::integral_constant<int, 0>{}, fa[0]);
+    static_for<0, NG>([&](auto Gc) __attribute__((always_inline)) {
+      constexpr int G = decltype(Gc)::value;
+      if constexpr (ABL & 4) {
+        if constexpr (G == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else if constexpr (G + 1 < NG) {
+        read_group(std::integral_constant<int, G + 1>{}, fa[(G + 1) & 1]);
+        lds_wait_group<WL_GRP>(fa[G & 1]);
+      } else {
+        lds_wait_group<0>(fa[G & 1]);
+      }
+      if constexpr (F1 && G == 0) asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+      static_for<0, WL_GRP>([&](auto Jc) __attribute__((always_inline)) {
+        constexpr int J = decltype(Jc)::value;
+        constexpr int n = G * WL_GRP + J;                 // MFMA gap of the step
+        constexpr int fr = frag_of(n);
+        const half8 af = __builtin_bit_cast(half8, fa[G & 1][J]);
+        if constexpr (ABL & 8) {
+          if constexpr (F1 && n == NM - 1) asm volatile("" : "=v"(acc1[PAR]));
+        } else if constexpr (fr >= 24) {
+          constexpr int m = fr - 24, ob = m >> 1, s = m & 1;   // FFN2: output block ob, k-step s of block i - 2
+          const rf_u32x4 hb = {hw[PAR][4 * s], hw[PAR][4 * s + 1], hw[PAR][4 * s + 2], hw[PAR][4 * s + 3]};
+          acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(half8, hb), acc[ob], 0, 0, 0);
+        } else {
+          constexpr int kk = fr;                           // FFN1: k-step kk of block i
+          // FFN1's accumulator lives in the VECTOR half of the register file (hipcc gives every MFMA of a kernel
+          // that uses accumulator registers an accumulator-half destination, and the GELU then paid one
+          // v_accvgpr_read per value): inline asm with vector-register C / D.  Nothing reads it before the next
+          // step's GELU (a barrier and hundreds of instructions away: no XDL-write hazard to pad by hand).
+          if constexpr (kk == 0) {
+            f32x16 b0 = {bq[0][0], bq[0][1], bq[0][2], bq[0][3], bq[1][0], bq[1][1], bq[1][2], bq[1][3],
+                         bq[2][0], bq[2][1], bq[2][2], bq[2][3], bq[3][0], bq[3][1], bq[3][2], bq[3][3]};
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(b0) : "v"(fa[G & 1][J]), "v"(xf[kk]));
+            acc1[PAR] = b0;
+          } else {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1[PAR]) : "v"(fa[G & 1][J]), "v"(xf[kk]));
+          }
+        }
+        if constexpr (GE) {   // GELU of block i - 1 (accumulator and h of the other parity): this gap's slots
+          constexpr int o0 = n * 256 / NM, o1 = (n + 1) * 256 / NM;
+          static_for<o0, o1>([&](auto Oc) __attribute__((always_inline)) {
+            gelu_slot<decltype(Oc)::value>(acc1[PAR ^ 1], gt, hw[PAR ^ 1]);
+          });
+        }
+        if constexpr (J == WL_GRP - 1 && !(ABL & 1)) {
+          // 12 pieces per step whatever the step holds: one per group, or two where the step has six groups
+          if constexpr (NG == 12) {
+            issue_piece(nsrc, ndst, G);
+          } else {
+            issue_piece(nsrc, ndst, 2 * G);
+            issue_piece(nsrc, ndst, 2 * G + 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  mlp_step(F_{}, T_{}, F_{}, P0{}, 0);
+  mlp_step(F_{}, T_{}, T_{}, P1{}, 1);
+#pragma unroll 1
+  for (int i = 2; i < 48; i += 2) {
+    mlp_step(T_{}, T_{}, T_{}, P0{}, i);
+    mlp_step(T_{}, T_{}, T_{}, P1{}, i + 1);
+  }
+  mlp_step(T_{}, F_{}, T_{}, P0{}, 48);
+  mlp_step(T_{}, F_{}, F_{}, P1{}, 49);
+  static_for<0, KS>([&](auto Kc) __attribute__((always_inline)) {   // + y (the fp16 operands still in registers)
+    constexpr int kk = decltype(Kc)::value;
+    acc[kk >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id_perm[kk & 1], __builtin_bit_cast(half8, xf[kk]), acc[kk >> 1], 0, 0, 0);
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pieces past the last step must land before the LDS is handed on
+  if (DBG) {
+    asm volatile("" : "+v"(acc[11]));
+    ts_ln2 = __builtin_amdgcn_s_memtime();
+  }
+
+  // ---- LayerNorm 2 over v = acc; x' -> HBM ------------------------------------------------------------
+  {
+    float sc, sh;
+    ln_stats(sc, sh);
+    _Float16* const dst = a.out + (tb * KS * 64 + lane) * 8;
+    const bool live = t0 + 32 * wave + r32 < M;   // the token whose 16-byte slots this lane stores
+    static_for<0, 12>([&](auto Fc) __attribute__((always_inline)) {
+      constexpr int fb = decltype(Fc)::value;
+      uint2 pk[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4v gv = param4(4, fb, g), be = param4(5, fb, g);
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (_Float16)fmaf(fmaf(acc[fb][4 * g + j], sc, sh), gv[j], be[j]);
+        pk[g] = __builtin_bit_cast(uint2, o);
+      }
+      // the 16-byte slot (token, 8 features) of the tiled layout is split between lanes c and c + 32: the packed
+      // quads 2 m and 2 m + 1 go through v_permlane32_swap and the wave then holds fragment 2 fb + m lane-linear
+      const auto sx0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+      const auto sy0 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+      const auto sx1 = __builtin_amdgcn_permlane32_swap(pk[2].x, pk[3].x, false, false);
+      const auto sy1 = __builtin_amdgcn_permlane32_swap(pk[2].y, pk[3].y, false, false);
+      if (live) {
+        *(uint4*)(dst + (size_t)(2 * fb) * 512) = make_uint4(sx0[0], sy0[0], sx0[1], sy0[1]);
+        *(uint4*)(dst + (size_t)(2 * fb + 1) * 512) = make_uint4(sx1[0], sy1[0], sx1[1], sy1[1]);
+      }
+    });
+  }
+  if (DBG && a.dbg && lane == 0 && blockIdx.x < 512) {   // the buffer holds 4096 waves x 8 floats
+    float* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+    const uint64_t te = __builtin_amdgcn_s_memtime();
+    d[0] = (float)(te - ts_entry);       // cycles, whole wave
+    d[1] = (float)(ts_a - ts_entry);     // prologue
+    d[2] = (float)(ts_ln1 - ts_a);       // out-projection (6 steps + residual)
+    d[3] = (float)(ts_b - ts_ln1);       // LayerNorm 1
+    d[4] = (float)(ts_ln2 - ts_b);       // MLP (50 steps + residual)
+    d[5] = (float)(te - ts_ln2);         // LayerNorm 2 + stores
+    d[6] = (float)t_wait;                // vmcnt wait + barrier, all 56 steps
+    d[7] = (float)(__builtin_amdgcn_s_memrealtime() - tr_entry);   // 100-MHz ticks, whole wave
+  }
+}
+
+int rf_launch_post_block(const rf_post_args& a, int token_slots, hipStream_t st) {
+  const dim3 grid((token_slots + PB_TOK - 1) / PB_TOK), block(PB_WAVES * 64);
+  const size_t lds = PB_LDS_BYTES;
+#define RF_PB_LAUNCH(D, A)                                                  \
+  do {                                                                      \
+    static rf_lds_attr attr_;   /* per instantiation, per device */         \
+    RF_HIP(rf_ensure_lds(attr_, (const void*)k_post_block<D, A>, lds));      \
+    hipLaunchKernelGGL((k_post_block<D, A>), grid, block, lds, st, a);       \
+    return RF_OK;                                                           \
+  } while (0)
+#ifdef RF_EXPERIMENTS
+  if (a.dbg || a.abl) {
+    switch (a.abl) {
+      case 1: RF_PB_LAUNCH(1, 1);
+      case 2: RF_PB_LAUNCH(1, 2);
+      case 3: RF_PB_LAUNCH(1, 3);
+      case 4: RF_PB_LAUNCH(1, 4);
+      case 8: RF_PB_LAUNCH(1, 8);
+      case 7: RF_PB_LAUNCH(1, 7);
+      default: RF_PB_LAUNCH(1, 0);
+    }
+  }
+#endif
+  RF_PB_LAUNCH(0, 0);
+#undef RF_PB_LAUNCH
+}

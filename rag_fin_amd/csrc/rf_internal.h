@@ -62,9 +62,11 @@ RF_KNOB(rf_knob_ffn2_ntb, 4)           // encoder: the same for the K = 1536 Lay
 RF_KNOB(rf_knob_gemm_tile, 3)          // encoder: GEMMs on k_gemm_tile (both operands through the LDS-DMA ring): 1 FFN2, 2 out-proj, 4 QKV, 8 FFN1
 RF_KNOB(rf_knob_encode_graph, 1)       // encoder: query-sized forwards replay a cached hipGraph
 RF_KNOB(rf_knob_linear_dbg, 0)         // encoder: k_linear_dma ablation bits (results wrong)
-RF_KNOB(rf_knob_debug_epi, 1)          // encoder: which kernel writes clock stamps (0 QKV, 1 FFN1, 2 attention)
+RF_KNOB(rf_knob_debug_epi, 1)          // encoder: which kernel writes clock stamps (0 QKV, 1 FFN1, 2 attention, 3 FFN2, 4 out-projection, 5 post block)
 RF_KNOB(rf_knob_att_heads, 1)          // encoder: heads per attention workgroup (1 | 2)
 RF_KNOB(rf_knob_one_query, 1)          // encoder: a single sequence of <= 32 tokens takes the fused QKV + attention launch
+RF_KNOB(rf_knob_post_block, 1)         // encoder: out-projection + MLP of a layer as one launch at >= 8192 token slots (encoder_post.hip)
+RF_KNOB(rf_knob_post_dbg, 0)           // encoder: k_post_block ablation bits (results wrong)
 RF_KNOB(rf_knob_gemm_tile_dma, 0)      // encoder: k_gemm_tile LDS-DMA issue: 0 = halves take turns, 8 pieces in a burst (product); 1 = every wave 4 pieces between its MFMAs; 2 = none (ablation)
 #undef RF_KNOB
 #ifdef RF_EXPERIMENTS

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--tune", default="", help="rf_set_tuning pairs, e.g. ffn2_ntb=4,linear_dma=0")
     ap.add_argument("--texts", action="store_true", help="also time the text -> tokenizer -> encoder path")
     ap.add_argument("--stamps", action="store_true", help="clock stamps of the last k_linear_dma launch")
-    ap.add_argument("--stamp-epi", type=int, default=1, help="0 = QKV, 1 = FFN1, 2 = attention, 3 = FFN2, 4 = out-projection")
+    ap.add_argument("--stamp-epi", type=int, default=1, help="0 = QKV, 1 = FFN1, 2 = attention, 3 = FFN2, 4 = out-projection, 5 = post block")
     ap.add_argument("--linear-dbg", type=int, default=0, help="ablation bits of k_linear_dma (results wrong)")
     args = ap.parse_args()
     import torch
@@ -86,6 +86,15 @@ def main():
                   "per item (x%.1f): QK+max %.0f, exp+sum %.0f, PV %.0f, scale+store %.0f" %
                   (ok.sum(), np.median(ntok), np.median(items), np.median(tot), np.median(stage), np.median(per),
                    np.median(qk / per), np.median(ex / per), np.median(pv / per), np.median(outp / per)))
+            return
+        if args.stamp_epi == 5:     # k_post_block: [workgroup][wave 0-3 of 8] x {cycles, prologue, out-proj, LN1, MLP, LN2, wait, steps}
+            st = buf.view(512, 8, 8).cpu().numpy()[:, :4]
+            ok = st[..., 0] > 0
+            tot, pro, pa, l1, pb, l2, wait, ticks = (st[..., i][ok] for i in range(8))
+            print("k_post_block stamps (last launch, %d waves, clock %.2f GHz): wave %.0f cycles = prologue %.0f + out-projection %.0f (6 steps x %.0f) + "
+                  "LayerNorm 1 %.0f + MLP %.0f (50 steps x %.0f) + LayerNorm 2 and stores %.0f; vmcnt wait + barrier %.0f per step" %
+                  (ok.sum(), np.median(tot / ticks) * 0.1, np.median(tot), np.median(pro), np.median(pa), np.median(pa) / 6, np.median(l1), np.median(pb),
+                   np.median(pb) / 50, np.median(l2), np.median(wait) / 56))
             return
         if args.stamp_epi in (3, 4):   # k_gemm_tile: [workgroup][wave] x {cycles, prologue, loop, wait in loop, epilogue, stages}
             st = buf.view(512, 8, 8).cpu().numpy()

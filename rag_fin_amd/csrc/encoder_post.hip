@@ -43,7 +43,7 @@
 // ---- the per-layer pack ---------------------------------------------------------------------------
 // pack[l][fragment F][lane][16 bytes]:
 //   F < 16:         parameters as fp32: b1 [1536], bo, g1, be1, b2, g2, be2 [384 each] (15 KiB), then zeros
-//   16 <= F < 304:  out-projection weights, standard fragment tiling [block 0..11][k-step 0..23]
+//   16 <= F < 304:  out-projection weights, standard fragment tiling, in ring order [step S 0..5][k-step 4 S + j, j 0..3][block 0..11]
 //   304 <= F:       the MLP stream [step i 0..49][fragment f 0..47], lane = 32 h + r:
 //     f < 24  (i < 48):  W1[32 i + r][perm(f, h, e)]                          FFN1 block i, k-step f
 //     f >= 24 (i >= 2):  W2[32 ob + r][32 (i - 2) + perm(s, h, e)], ob = (f - 24) >> 1, s = (f - 24) & 1
@@ -80,7 +80,9 @@ __global__ void __launch_bounds__(256) k_post_pack_build(const PackSrc w, uint4*
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.f;
   if (F < 16 + PB_STEPS_A * PB_FRAGS) {
-    const int b = (F - 16) / 24, kk = (F - 16) % 24;
+    // step S = k-steps 4 S .. 4 S + 3 of ALL 12 feature blocks: fragment (F - 16) % 48 = 12 j + b
+    const int S = (F - 16) / PB_FRAGS, q = (F - 16) % PB_FRAGS;
+    const int b = q % 12, kk = 4 * S + q / 12;
     const _Float16* src = w.ao_w + ((size_t)l * HID + 32 * b + r) * HID + 16 * kk + 8 * h;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = src[e];
@@ -129,41 +131,39 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// ---- GELU of one FFN1 block (16 values per lane), cut into 256 slots ------------------------------
-// The arithmetic of gelu_erf_s (encoder.hip): h(y) = y (1/2 + yc Q(t)), yc = y clamped to +-3.2 sqrt 2,
-// t = yc^2 / 3.2^2 - 1, Q the degree-10 erf polynomial with 1 / (2 sqrt 2) folded in; plain fp32 only
-// (packed fp32 does not issue under MFMAs).  Slot O: quad O >> 6 (accumulator registers 4 q .. 4 q + 3,
-// four independent dependency chains), within it 15 stages x 4 values, then two fp16 pair conversions.
+// ---- GELU of one FFN1 block (16 values per lane), cut into 136 slots -------------------------------
+// gelu(y) = y Phi(y) = max(y, 0) - |y| Phi(-|y|), and log2 Phi(-t) is so smooth that a degree-5 polynomial in
+// t = |y| (weighted minimax fit on [0, 6], tools/fit_gelu.py) gives |error| <= 6.4e-7 over |y| <= 40 -- thirty
+// times closer to the exact erf form than the degree-10 erf polynomial of the other GEMM paths (1.9e-5) -- in
+// 7 plain operations + 1 v_exp_f32 per value instead of 15: the kernel's waves are bound by their VALU issue.
+// The leading coefficient is negative, so beyond the fitted range the exponent runs to -inf, 2^P to 0 and the
+// value to max(y, 0): no clamp.  |y| and -|y| are source modifiers (free).  Plain fp32 only (packed fp32 does
+// not issue under MFMAs).  Slot O: quad O / 34 (accumulator registers 4 q .. 4 q + 3, four independent chains);
+// within it 5 Horner stages x 4 values, the exponentials alternating with the (independent) max(y, 0), the
+// final fma, then two fp16 pair conversions.
+#define GELU_SLOTS 136
 struct GeluTmp {
-  float yc[4], t[4], p[4];
+  float p[4], r[4];
 };
-__device__ constexpr float kGeluK[11] = {8.469007444e-04f, -2.387454268e-03f, 3.280109027e-03f, -5.588355009e-03f,
-                                         1.136882324e-02f, -1.921003498e-02f, 2.861942165e-02f, -4.021260887e-02f,
-                                         5.456056446e-02f, -7.682786137e-02f, 1.560353935e-01f};
+__device__ constexpr float kGeluP[6] = {-1.000037670135498f, -1.1507878303527832f, -0.45999258756637573f,
+                                        -0.051827218383550644f, 0.007084481883794069f, -0.0004732970555778593f};
 template <int O>
 __device__ __forceinline__ void gelu_slot(const f32x16& y, GeluTmp& g, uint32_t (&hw)[8]) {
-  constexpr int quad = O >> 6, w = O & 63;
-  if constexpr (w < 60) {
+  constexpr int quad = O / 34, w = O % 34;
+  if constexpr (w < 20) {
     constexpr int st = w >> 2, v = w & 3;
-    const float yv = y[4 * quad + v];
-    if constexpr (st == 0) {
-      constexpr float CP = 4.52548360824585f;   // 3.2 sqrt 2
-      g.yc[v] = __builtin_amdgcn_fmed3f(yv, -CP, CP);
-    } else if constexpr (st == 1) {
-      g.t[v] = g.yc[v] * g.yc[v];
-    } else if constexpr (st == 2) {
-      g.t[v] = __builtin_fmaf(g.t[v], 0.09765625f, -1.f);
-    } else if constexpr (st == 3) {
-      g.p[v] = __builtin_fmaf(g.t[v], kGeluK[0], kGeluK[1]);
-    } else if constexpr (st <= 12) {
-      g.p[v] = __builtin_fmaf(g.t[v], g.p[v], kGeluK[st - 2]);
-    } else if constexpr (st == 13) {
-      g.p[v] = __builtin_fmaf(g.yc[v], g.p[v], 0.5f);
-    } else {
-      g.p[v] = yv * g.p[v];
-    }
-  } else if constexpr (w < 62) {
-    constexpr int pr = w - 60;
+    const float t = __builtin_fabsf(y[4 * quad + v]);
+    if constexpr (st == 0) g.p[v] = __builtin_fmaf(kGeluP[5], t, kGeluP[4]);
+    else g.p[v] = __builtin_fmaf(g.p[v], t, kGeluP[4 - st]);
+  } else if constexpr (w < 28) {
+    constexpr int v = (w - 20) >> 1;
+    if constexpr (((w - 20) & 1) == 0) g.p[v] = __builtin_amdgcn_exp2f(g.p[v]);
+    else g.r[v] = __builtin_fmaxf(y[4 * quad + v], 0.f);
+  } else if constexpr (w < 32) {
+    constexpr int v = w - 28;
+    g.p[v] = __builtin_fmaf(-__builtin_fabsf(y[4 * quad + v]), g.p[v], g.r[v]);
+  } else {
+    constexpr int pr = w - 32;
     const half2v o = {(_Float16)g.p[2 * pr], (_Float16)g.p[2 * pr + 1]};
     hw[2 * quad + pr] = __builtin_bit_cast(uint32_t, o);
   }
@@ -171,8 +171,48 @@ __device__ __forceinline__ void gelu_slot(const f32x16& y, GeluTmp& g, uint32_t 
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// A 16-byte global load the compiler does not count: it sits between LDS-DMA pieces (inline asm, invisible to hipcc),
+// and hipcc's own vmcnt for a plain load -- "all but my N younger loads" -- would count the younger PIECES as
+// loads and wait for the ring (stamps: the 24 residual MFMAs took 2 700 cycles waiting for pieces issued moments
+// before).  The destination is valid only after a hand-placed s_waitcnt that covers it (the counted waits of the
+// ring steps do: they retire everything older than the previous step's issues).
+__device__ __forceinline__ void gload16(rf_u32x4& d, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+
+// ---- LDS fragment reads of a ring step: pairs of fragments, four register pairs, three pairs ahead ----
+// One ds_read_b128 per MFMA, all four waves of the CU: the LDS runs at half its rate and a read issued four
+// MFMAs (128 cycles) ahead is late (stamps: 60 cycles per MFMA in the out-projection steps with groups of four
+// read one group ahead).  Pair g (MFMAs 2 g, 2 g + 1) is read while pair g - 3 computes: six MFMAs of lead,
+// the same 32 registers.  run_step<NM>(frag_of, sa, body): frag_of(n) = fragment of MFMA n (a constexpr
+// callable), body(n_c, fragment registers) issues MFMA n and whatever rides in its gap.
+template <int N>
+__device__ __forceinline__ void lds_wait_pair(rf_u32x4 (&d)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(d[0]), "+v"(d[1]) : "n"(N));
+}
+template <int NM, class FragOf, class Body>
+__device__ __forceinline__ void run_step(FragOf frag_of, uint32_t sa, Body&& body) {
+  constexpr int NP = NM / 2;   // pairs
+  rf_u32x4 fa[4][2];
+  auto read_pair = [&](auto Gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(Gc)::value;
+    lds_read_frag<frag_of(2 * G)>(fa[G & 3][0], sa);
+    lds_read_frag<frag_of(2 * G + 1)>(fa[G & 3][1], sa);
+  };
+  static_for<0, (NP < 3 ? NP : 3)>([&](auto Gc) __attribute__((always_inline)) { read_pair(Gc); });
+  static_for<0, NP>([&](auto Gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(Gc)::value;
+    if constexpr (G + 3 < NP) read_pair(std::integral_constant<int, G + 3>{});
+    constexpr int newer = (NP - 1 - G) < 3 ? (NP - 1 - G) : 3;   // pairs read after pair G
+    lds_wait_pair<2 * newer>(fa[G & 3]);
+    body(std::integral_constant<int, 2 * G>{}, fa[G & 3][0]);
+    body(std::integral_constant<int, 2 * G + 1>{}, fa[G & 3][1]);
+  });
+}
+
+
 // DBG: clock stamps per wave into a.dbg.  ABL (experiments build; results wrong): 1 = no LDS-DMA in the MLP
-// steps, 2 = no GELU, 4 = no LDS fragment reads in the MLP steps, 8 = no MFMAs in the MLP steps.
+// steps, 2 = no GELU, 8 = no MFMAs in the MLP steps.
 template <int DBG, int ABL>
 __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_block(const rf_post_args a) {
   constexpr int KS = HID / 16;   // 24
@@ -214,11 +254,13 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   // Prologue in dependency order: the wave's attention output (first MFMA), the parameter block and the first
   // two ring steps, then the token count (every read above is legal for any workgroup: buffers are padded).
   rf_u32x4 xf[KS];   // B-operand fragments: first ctx, then y
-  {
-    const _Float16* src = a.ctx + (tb * KS * 64 + lane) * 8;
+  const _Float16* const csrc = a.ctx + (tb * KS * 64 + lane) * 8;
+  const _Float16* const rsrc = a.res + (tb * KS * 64 + lane) * 8;
+  // only the k-steps of the first two ring steps here; the rest of the tile (and the residual) is fetched a few
+  // loads at a time under the out-projection's MFMAs: 24 loads in a row stalled the issuing wave for ~4 000 cycles
+  // (every CU asks for its 96 KB at the same moment: stamps)
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) xf[kk] = *(const rf_u32x4*)(src + (size_t)kk * 512);
-  }
+  for (int kk = 0; kk < 8; ++kk) xf[kk] = *(const rf_u32x4*)(csrc + (size_t)kk * 512);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int f = wave + 4 * q;   // parameter fragment (15 of them)
@@ -253,11 +295,13 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
     });
   };
   const uint32_t slots_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)slots + lane_off;
-  auto sync_step = [&]() __attribute__((always_inline)) {
+  // extra = vector-memory operations the previous step issued besides its 12 ring pieces (plain loads)
+  auto sync_step = [&](auto extra_c) __attribute__((always_inline)) {
+    constexpr int EXTRA = decltype(extra_c)::value;
     uint64_t ts0 = 0;
     if (DBG) ts0 = __builtin_amdgcn_s_memtime();
-    // my pieces of this step have landed (those of the next step, 12, may stay in flight) ...
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB_PW) : "memory");
+    // my pieces of this step have landed (what the previous step issued may stay in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB_PW + EXTRA) : "memory");
     // ... after the barrier everybody's have, and everybody has read the previous step (its slot is free)
     __builtin_amdgcn_s_barrier();
     if (DBG) t_wait += __builtin_amdgcn_s_memtime() - ts0;
@@ -279,47 +323,37 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   // ---- phase A: out-projection ------------------------------------------------------------------------
   f32x16 acc[12];   // [feature block]: acc_o, later acc2
   load_vec(0, acc);  // accumulator input = bias
-  rf_u32x4 xr[KS];   // the layer input (residual), fetched under the last two steps
+  rf_u32x4 xr[KS];   // the layer input (residual)
   if (DBG) ts_a = __builtin_amdgcn_s_memtime();
+  uint64_t ts_step[PB_STEPS_A + 1];
+  // Step S = k-steps 4 S .. 4 S + 3 of all 12 feature blocks (48 MFMAs on 12 independent accumulation chains; fragment
+  // m of the slot = k-step m / 12, block m % 12), so the tile's k-steps are needed four per step.  Eight loads (gload16)
+  // ride in every step but the last, one after every sixth MFMA: steps 0, 1 the k-steps 8..23 of ctx, steps 2-4 the
+  // residual.  (They are older than the ring pieces issued after them: the counted waits below let the previous
+  // step's 12 pieces AND its 8 loads stay in flight.)
   static_for<0, PB_STEPS_A>([&](auto Sc) __attribute__((always_inline)) {
     constexpr int S = decltype(Sc)::value;
-    sync_step();
-    if constexpr (S == PB_STEPS_A - 2) {   // older than this step's pieces: the counted waits only over-wait
-      const _Float16* rsrc = a.res + (tb * KS * 64 + lane) * 8;
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) xr[kk] = *(const rf_u32x4*)(rsrc + (size_t)kk * 512);
-    }
+    sync_step(std::integral_constant<int, (S >= 1 ? 8 : 0)>{});
     const uint32_t sa = slots_a + (uint32_t)((S % PB_SLOTS) * PB_FRAGS * 1024);
     const char* const nsrc = step_src(S + 2);
     const uint32_t ndst = step_dst(S + 2);
-    rf_u32x4 fa[2][WL_GRP];
-    // MFMA m of the step: feature block 2 S + (m & 1), k-step m >> 1 -- the two blocks' accumulation chains alternate
-    auto read_group = [&](auto Gc, rf_u32x4 (&d)[WL_GRP]) __attribute__((always_inline)) {
-      constexpr int G = decltype(Gc)::value;
-      lds_read_frag<2 * G>(d[0], sa);
-      lds_read_frag<24 + 2 * G>(d[1], sa);
-      lds_read_frag<2 * G + 1>(d[2], sa);
-      lds_read_frag<24 + 2 * G + 1>(d[3], sa);
-    };
-    read_group(std::integral_constant<int, 0>{}, fa[0]);
-    static_for<0, PB_FRAGS / WL_GRP>([&](auto Gc) __attribute__((always_inline)) {
-      constexpr int G = decltype(Gc)::value;
-      if constexpr (G + 1 < PB_FRAGS / WL_GRP) {
-        read_group(std::integral_constant<int, G + 1>{}, fa[(G + 1) & 1]);
-        lds_wait_group<WL_GRP>(fa[G & 1]);
-      } else {
-        lds_wait_group<0>(fa[G & 1]);
+    run_step<PB_FRAGS>([](int m) constexpr { return m; }, sa, [&](auto Mc, const rf_u32x4& af) __attribute__((always_inline)) {
+      constexpr int m = decltype(Mc)::value, fb = m % 12, kk = 4 * S + m / 12;
+      acc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, xf[kk]), acc[fb], 0, 0, 0);
+      if constexpr ((m & 3) == 3) issue_piece(nsrc, ndst, m >> 2);
+      if constexpr (m % 6 == 5 && S < PB_STEPS_A - 1) {
+        constexpr int q = 8 * S + m / 6;   // 0..39
+        if constexpr (q < 16) gload16(xf[8 + q], csrc + (size_t)(8 + q) * 512);
+        else gload16(xr[q - 16], rsrc + (size_t)(q - 16) * 512);
       }
-      static_for<0, WL_GRP>([&](auto Jc) __attribute__((always_inline)) {
-        constexpr int J = decltype(Jc)::value;
-        constexpr int m = G * WL_GRP + J, fb = 2 * S + (m & 1), kk = m >> 1;
-        acc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[G & 1][J]),
-                                                         __builtin_bit_cast(half8, xf[kk]), acc[fb], 0, 0, 0);
-      });
-      issue_piece(nsrc, ndst, G);
       __builtin_amdgcn_sched_barrier(0);
     });
+    if (DBG) ts_step[S] = __builtin_amdgcn_s_memtime();
   });
+  // step 4's loads (the last third of the residual) may still be in flight: everything but step 5's 12 pieces has landed
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) : "n"(PB_PW));
+  asm volatile("" : "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]), "+v"(xr[15]));
+  asm volatile("" : "+v"(xr[16]), "+v"(xr[17]), "+v"(xr[18]), "+v"(xr[19]), "+v"(xr[20]), "+v"(xr[21]), "+v"(xr[22]), "+v"(xr[23]));
   static_for<0, KS>([&](auto Kc) __attribute__((always_inline)) {   // + x
     constexpr int kk = decltype(Kc)::value;
     acc[kk >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id_std[kk & 1], __builtin_bit_cast(half8, xr[kk]), acc[kk >> 1], 0, 0, 0);
@@ -387,10 +421,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   auto mlp_step = [&](auto f2c, auto f1c, auto gec, auto parc, int i) __attribute__((always_inline)) {
     constexpr bool F2 = decltype(f2c)::value, F1 = decltype(f1c)::value, GE = decltype(gec)::value && !(ABL & 2);
     constexpr int PAR = decltype(parc)::value;
-    constexpr int NG = (F2 ? 6 : 0) + (F1 ? 6 : 0);      // LDS read groups = groups of 4 MFMAs
-    constexpr int NM = NG * WL_GRP;                       // MFMA gaps of the step
+    constexpr int NM = (F2 ? 24 : 0) + (F1 ? 24 : 0);    // MFMAs (= gaps) of the step
     const int S = PB_STEPS_A + i;
-    sync_step();
+    sync_step(std::integral_constant<int, 0>{});
     const uint32_t sa = slots_a + (uint32_t)((S % PB_SLOTS) * PB_FRAGS * 1024);
     const char* const nsrc = step_src(S + 2);
     const uint32_t ndst = step_dst(S + 2);
@@ -402,74 +435,49 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
       asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(bq[2]) : "v"(ba));
       asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(bq[3]) : "v"(ba));
     }
-    rf_u32x4 fa[2][WL_GRP];
     // MFMA gap n of the step -> its A fragment.  In a full step the two GEMMs ALTERNATE (n even: FFN2 number n / 2,
-    // n odd: FFN1 k-step n / 2): FFN1 is one chain of 24 dependent MFMAs on a vector-register accumulator and a
-    // dependent MFMA of that form issues ~10 cycles late (stamps: 2 020 against 1 786 cycles per step with the
-    // chain back to back) -- with an independent FFN2 product between two links the chain never waits.
+    // n odd: FFN1 k-step n / 2), so that a pair of LDS reads feeds one MFMA of each accumulation chain.
     auto frag_of = [](int n) constexpr { return (F2 && F1) ? ((n & 1) ? (n >> 1) : 24 + (n >> 1)) : (F2 ? 24 + n : n); };
-    auto read_group = [&](auto Gc, rf_u32x4 (&d)[WL_GRP]) __attribute__((always_inline)) {
-      constexpr int G = decltype(Gc)::value;
-      lds_read_frag<frag_of(4 * G + 0)>(d[0], sa);
-      lds_read_frag<frag_of(4 * G + 1)>(d[1], sa);
-      lds_read_frag<frag_of(4 * G + 2)>(d[2], sa);
-      lds_read_frag<frag_of(4 * G + 3)>(d[3], sa);
-    };
-    if constexpr (!(ABL & 4)) read_group(std::integral_constant<int, 0>{}, fa[0]);
-    static_for<0, NG>([&](auto Gc) __attribute__((always_inline)) {
-      constexpr int G = decltype(Gc)::value;
-      if constexpr (ABL & 4) {
-        if constexpr (G == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      } else if constexpr (G + 1 < NG) {
-        read_group(std::integral_constant<int, G + 1>{}, fa[(G + 1) & 1]);
-        lds_wait_group<WL_GRP>(fa[G & 1]);
+    run_step<NM>(frag_of, sa, [&](auto Nc, const rf_u32x4& afr) __attribute__((always_inline)) {
+      constexpr int n = decltype(Nc)::value;             // MFMA gap of the step
+      constexpr int fr = frag_of(n);
+      if constexpr (F1 && n == 0) asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));   // landed: older than the first pair
+      if constexpr (ABL & 8) {
+        if constexpr (F1 && n == NM - 1) asm volatile("" : "=v"(acc1[PAR]));
+      } else if constexpr (fr >= 24) {
+        constexpr int m = fr - 24, ob = m >> 1, s = m & 1;   // FFN2: output block ob, k-step s of block i - 2
+        const rf_u32x4 hb = {hw[PAR][4 * s], hw[PAR][4 * s + 1], hw[PAR][4 * s + 2], hw[PAR][4 * s + 3]};
+        acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, afr), __builtin_bit_cast(half8, hb), acc[ob], 0, 0, 0);
       } else {
-        lds_wait_group<0>(fa[G & 1]);
-      }
-      if constexpr (F1 && G == 0) asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
-      static_for<0, WL_GRP>([&](auto Jc) __attribute__((always_inline)) {
-        constexpr int J = decltype(Jc)::value;
-        constexpr int n = G * WL_GRP + J;                 // MFMA gap of the step
-        constexpr int fr = frag_of(n);
-        const half8 af = __builtin_bit_cast(half8, fa[G & 1][J]);
-        if constexpr (ABL & 8) {
-          if constexpr (F1 && n == NM - 1) asm volatile("" : "=v"(acc1[PAR]));
-        } else if constexpr (fr >= 24) {
-          constexpr int m = fr - 24, ob = m >> 1, s = m & 1;   // FFN2: output block ob, k-step s of block i - 2
-          const rf_u32x4 hb = {hw[PAR][4 * s], hw[PAR][4 * s + 1], hw[PAR][4 * s + 2], hw[PAR][4 * s + 3]};
-          acc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(half8, hb), acc[ob], 0, 0, 0);
+        constexpr int kk = fr;                           // FFN1: k-step kk of block i
+        // FFN1's accumulator lives in the VECTOR half of the register file (hipcc gives every MFMA of a kernel
+        // that uses accumulator registers an accumulator-half destination, and the GELU then paid one
+        // v_accvgpr_read per value): inline asm with vector-register C / D.  Nothing reads it before the next
+        // step's GELU (a barrier and hundreds of instructions away: no XDL-write hazard to pad by hand).
+        if constexpr (kk == 0) {
+          f32x16 b0 = {bq[0][0], bq[0][1], bq[0][2], bq[0][3], bq[1][0], bq[1][1], bq[1][2], bq[1][3],
+                       bq[2][0], bq[2][1], bq[2][2], bq[2][3], bq[3][0], bq[3][1], bq[3][2], bq[3][3]};
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(b0) : "v"(afr), "v"(xf[kk]));
+          acc1[PAR] = b0;
         } else {
-          constexpr int kk = fr;                           // FFN1: k-step kk of block i
-          // FFN1's accumulator lives in the VECTOR half of the register file (hipcc gives every MFMA of a kernel
-          // that uses accumulator registers an accumulator-half destination, and the GELU then paid one
-          // v_accvgpr_read per value): inline asm with vector-register C / D.  Nothing reads it before the next
-          // step's GELU (a barrier and hundreds of instructions away: no XDL-write hazard to pad by hand).
-          if constexpr (kk == 0) {
-            f32x16 b0 = {bq[0][0], bq[0][1], bq[0][2], bq[0][3], bq[1][0], bq[1][1], bq[1][2], bq[1][3],
-                         bq[2][0], bq[2][1], bq[2][2], bq[2][3], bq[3][0], bq[3][1], bq[3][2], bq[3][3]};
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(b0) : "v"(fa[G & 1][J]), "v"(xf[kk]));
-            acc1[PAR] = b0;
-          } else {
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1[PAR]) : "v"(fa[G & 1][J]), "v"(xf[kk]));
-          }
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1[PAR]) : "v"(afr), "v"(xf[kk]));
         }
-        if constexpr (GE) {   // GELU of block i - 1 (accumulator and h of the other parity): this gap's slots
-          constexpr int o0 = n * 256 / NM, o1 = (n + 1) * 256 / NM;
-          static_for<o0, o1>([&](auto Oc) __attribute__((always_inline)) {
-            gelu_slot<decltype(Oc)::value>(acc1[PAR ^ 1], gt, hw[PAR ^ 1]);
-          });
+      }
+      if constexpr (GE) {   // GELU of block i - 1 (accumulator and h of the other parity): this gap's slots
+        constexpr int o0 = n * GELU_SLOTS / NM, o1 = (n + 1) * GELU_SLOTS / NM;
+        static_for<o0, o1>([&](auto Oc) __attribute__((always_inline)) {
+          gelu_slot<decltype(Oc)::value>(acc1[PAR ^ 1], gt, hw[PAR ^ 1]);
+        });
+      }
+      if constexpr (!(ABL & 1)) {
+        // 12 pieces per step whatever the step holds: one per four MFMAs, or one per two where the step has 24
+        if constexpr (NM == 48) {
+          if constexpr ((n & 3) == 3) issue_piece(nsrc, ndst, n >> 2);
+        } else {
+          if constexpr ((n & 1) == 1) issue_piece(nsrc, ndst, n >> 1);
         }
-        if constexpr (J == WL_GRP - 1 && !(ABL & 1)) {
-          // 12 pieces per step whatever the step holds: one per group, or two where the step has six groups
-          if constexpr (NG == 12) {
-            issue_piece(nsrc, ndst, G);
-          } else {
-            issue_piece(nsrc, ndst, 2 * G);
-            issue_piece(nsrc, ndst, 2 * G + 1);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
+      }
+      __builtin_amdgcn_sched_barrier(0);
     });
   };
   using T_ = std::true_type;
@@ -535,6 +543,10 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
     d[5] = (float)(te - ts_ln2);         // LayerNorm 2 + stores
     d[6] = (float)t_wait;                // vmcnt wait + barrier, all 56 steps
     d[7] = (float)(__builtin_amdgcn_s_memrealtime() - tr_entry);   // 100-MHz ticks, whole wave
+    float* d2 = d + 4 * 8;               // the rows of waves 4-7 (the workgroup has four): out-projection step by step
+    d2[0] = (float)(ts_step[0] - ts_a);
+    for (int q = 1; q < PB_STEPS_A; ++q) d2[q] = (float)(ts_step[q] - ts_step[q - 1]);
+    d2[6] = (float)(ts_ln1 - ts_step[PB_STEPS_A - 1]);   // residual MFMAs
   }
 }
 
@@ -554,9 +566,7 @@ int rf_launch_post_block(const rf_post_args& a, int token_slots, hipStream_t st)
       case 1: RF_PB_LAUNCH(1, 1);
       case 2: RF_PB_LAUNCH(1, 2);
       case 3: RF_PB_LAUNCH(1, 3);
-      case 4: RF_PB_LAUNCH(1, 4);
       case 8: RF_PB_LAUNCH(1, 8);
-      case 7: RF_PB_LAUNCH(1, 7);
       default: RF_PB_LAUNCH(1, 0);
     }
   }

@@ -88,13 +88,25 @@ def main():
                    np.median(qk / per), np.median(ex / per), np.median(pv / per), np.median(outp / per)))
             return
         if args.stamp_epi == 5:     # k_post_block: [workgroup][wave 0-3 of 8] x {cycles, prologue, out-proj, LN1, MLP, LN2, wait, steps}
-            st = buf.view(512, 8, 8).cpu().numpy()[:, :4]
+            full = buf.view(512, 8, 8).cpu().numpy()
+            st = full[:, :4]
+            ex = full[:, 4:]
+            okx = ex[..., 0] > 0
+            if okx.any():
+                print("out-projection step by step (cycles, medians): " + " ".join("%.0f" % np.median(ex[..., q][okx]) for q in range(6)) +
+                      "; residual MFMAs %.0f" % np.median(ex[..., 6][okx]))
             ok = st[..., 0] > 0
-            tot, pro, pa, l1, pb, l2, wait, ticks = (st[..., i][ok] for i in range(8))
-            print("k_post_block stamps (last launch, %d waves, clock %.2f GHz): wave %.0f cycles = prologue %.0f + out-projection %.0f (6 steps x %.0f) + "
-                  "LayerNorm 1 %.0f + MLP %.0f (50 steps x %.0f) + LayerNorm 2 and stores %.0f; vmcnt wait + barrier %.0f per step" %
-                  (ok.sum(), np.median(tot / ticks) * 0.1, np.median(tot), np.median(pro), np.median(pa), np.median(pa) / 6, np.median(l1), np.median(pb),
-                   np.median(pb) / 50, np.median(l2), np.median(wait) / 56))
+            for name, sel in (("all workgroups", slice(0, 512)), ("workgroups 0-255 (first on their CU)", slice(0, 256)),
+                              ("workgroups 256-511", slice(256, 512))):
+                sub = st[sel]
+                ok = sub[..., 0] > 0
+                if not ok.any():
+                    continue
+                tot, pro, pa, l1, pb, l2, wait, ticks = (sub[..., i][ok] for i in range(8))
+                print("k_post_block stamps, %s (last launch, %d waves, clock %.2f GHz): wave %.0f cycles = prologue %.0f + out-projection %.0f "
+                      "(6 steps x %.0f) + LayerNorm 1 %.0f + MLP %.0f (50 steps x %.0f) + LayerNorm 2 and stores %.0f; vmcnt wait + barrier %.0f per step" %
+                      (name, ok.sum(), np.median(tot / ticks) * 0.1, np.median(tot), np.median(pro), np.median(pa), np.median(pa) / 6, np.median(l1),
+                       np.median(pb), np.median(pb) / 50, np.median(l2), np.median(wait) / 56))
             return
         if args.stamp_epi in (3, 4):   # k_gemm_tile: [workgroup][wave] x {cycles, prologue, loop, wait in loop, epilogue, stages}
             st = buf.view(512, 8, 8).cpu().numpy()

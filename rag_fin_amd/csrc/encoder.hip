@@ -2054,6 +2054,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
       hipLaunchKernelGGL(k_qkv_attn_one, dim3(c.heads), dim3(256), 0, st, x, qkv_t,
                          (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, m_ptr, ws.ctx);
     } else {
+    if (!(l > 0 && rf_knob_post_block && rf_knob_post_qkv && tiles >= 8192))   // else: written by the previous layer's k_post_block
     launch_linear<EPI_BIAS>(x, HID, qkv_t, (const _Float16*)w.qkv_b + (size_t)l * 3 * HID, ws.qkv,
                             3 * HID, tiles, m_ptr, nullptr, nullptr, nullptr, 0.f, ws.pre, st);
     if (T <= 32 * ATT_MAX_KB) {
@@ -2085,6 +2086,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
       pa.ctx = ws.ctx;
       pa.res = x;
       pa.out = y;
+      pa.qkv_out = (rf_knob_post_qkv && l + 1 < L) ? ws.qkv : nullptr;   // the next layer's Q | K | V in the same launch
       pa.pack = enc->post_t + (size_t)l * rf_post_pack_elems() / 8;
       pa.eps = c.ln_eps;
       pa.m_ptr = m_ptr;

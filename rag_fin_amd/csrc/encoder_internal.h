@@ -36,8 +36,12 @@ __device__ __forceinline__ size_t toff(int t, int f, int KSf) {
 #define PB_STEPS_B 50   // ring steps of the MLP part: 48 intermediate blocks + 2 of pipeline drain
 #define PB_FRAGS 48     // 1-KiB fragments per ring step
 #define PB_PARAM_FRAGS 15   // fp32 parameter block: b1 [1536], bo, g1, be1, b2, g2, be2 [384 each] = 15 KiB
+#define PB_STEPS_C 18   // ring steps of the NEXT layer's QKV projection: 36 feature blocks, two per step
+#define PB_QB_FRAGS 8   // the next layer's QKV bias as fp32 [1152] (4.5 KiB), padded
 // per-layer pack the kernel reads: [parameters, padded to 16 fragments][out-projection 288][MLP stream 2400]
-#define PB_PACK_FRAGS (16 + (PB_STEPS_A + PB_STEPS_B) * PB_FRAGS)
+// [QKV of the next layer 864][its bias 8]
+#define PB_RING_FRAGS ((PB_STEPS_A + PB_STEPS_B + PB_STEPS_C) * PB_FRAGS)
+#define PB_PACK_FRAGS (16 + PB_RING_FRAGS + PB_QB_FRAGS)
 static inline size_t rf_post_pack_elems(void) { return (size_t)PB_PACK_FRAGS * 512; }   // halfs per layer
 // row-major weights / biases of all L layers -> pack [L][PB_PACK_FRAGS][64 lanes][16 B]
 void rf_launch_post_pack_build(const rf_encoder_weights* w, void* pack, int L, hipStream_t st);
@@ -45,6 +49,7 @@ struct rf_post_args {
   const _Float16* ctx;      // [Mpad, 384] tiled: attention output
   const _Float16* res;      // [Mpad, 384] tiled: the layer's input (residual of the first LayerNorm)
   _Float16* out;            // [Mpad, 384] tiled: the layer's output
+  _Float16* qkv_out;        // [Mpad, 1152] tiled: Q | K | V of the NEXT layer (its weights are in this layer's pack), or nullptr
   const uint4* pack;        // this layer's pack (rf_launch_post_pack_build)
   float eps;
   const int32_t* m_ptr;     // packed token count

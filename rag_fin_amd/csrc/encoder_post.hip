@@ -47,10 +47,11 @@
 //   304 <= F:       the MLP stream [step i 0..49][fragment f 0..47], lane = 32 h + r:
 //     f < 24  (i < 48):  W1[32 i + r][perm(f, h, e)]                          FFN1 block i, k-step f
 //     f >= 24 (i >= 2):  W2[32 ob + r][32 (i - 2) + perm(s, h, e)], ob = (f - 24) >> 1, s = (f - 24) & 1
+//   then [QKV of layer l + 1: 18 steps x 48 fragments, k-permuted][its bias as fp32, 8 fragments] (zeros in the last layer)
 //   perm(q, h, e) = 32 (q >> 1) + 16 (q & 1) + 8 (e >> 2) + 4 h + (e & 3): the feature that register
 //   8 (q & 1) + e of a 32x32 accumulator of block q >> 1 holds in lane half h.  Unused fragments are zero.
 struct PackSrc {
-  const _Float16 *ao_w, *ff1_w, *ff2_w, *ff1_b, *ao_b, *ln1_g, *ln1_b, *ff2_b, *ln2_g, *ln2_b;
+  const _Float16 *ao_w, *ff1_w, *ff2_w, *ff1_b, *ao_b, *ln1_g, *ln1_b, *ff2_b, *ln2_g, *ln2_b, *qkv_w, *qkv_b;
 };
 __global__ void __launch_bounds__(256) k_post_pack_build(const PackSrc w, uint4* __restrict__ pack, int L) {
   constexpr int I = 4 * HID;
@@ -86,6 +87,30 @@ __global__ void __launch_bounds__(256) k_post_pack_build(const PackSrc w, uint4*
     const _Float16* src = w.ao_w + ((size_t)l * HID + 32 * b + r) * HID + 16 * kk + 8 * h;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = src[e];
+  } else if (F >= 16 + PB_RING_FRAGS) {
+    // QKV bias of layer l + 1 as fp32
+    float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int j = ((F - 16 - PB_RING_FRAGS) * 64 + lane) * 4;
+    if (l + 1 < L && j < 3 * HID) {
+      const _Float16* p = w.qkv_b + (size_t)(l + 1) * 3 * HID + j;
+      o4 = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+    }
+    pack[idx] = __builtin_bit_cast(uint4, o4);
+    return;
+  } else if (F >= 16 + (PB_STEPS_A + PB_STEPS_B) * PB_FRAGS) {
+    // QKV weights of layer l + 1, k-permuted (B operand = x' as the accumulator leaves it): step t = blocks 2 t, 2 t + 1,
+    // fragment m of the step = block 2 t + (m & 1), k-step m >> 1 (the two accumulation chains alternate)
+    const int q = F - 16 - (PB_STEPS_A + PB_STEPS_B) * PB_FRAGS;
+    const int t = q / PB_FRAGS, m = q % PB_FRAGS;
+    const int blk = 2 * t + (m & 1), ks = m >> 1;
+    if (l + 1 < L) {
+      const _Float16* src = w.qkv_w + ((size_t)(l + 1) * 3 * HID + 32 * blk + r) * HID + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = src[e];
+        o[4 + e] = src[8 + e];
+      }
+    }
   } else {
     const int i = (F - 16 - PB_STEPS_A * PB_FRAGS) / PB_FRAGS, f = (F - 16 - PB_STEPS_A * PB_FRAGS) % PB_FRAGS;
     const _Float16* src = nullptr;
@@ -119,6 +144,8 @@ void rf_launch_post_pack_build(const rf_encoder_weights* w, void* pack, int L, h
   ps.ff2_b = (const _Float16*)w->ff2_b;
   ps.ln2_g = (const _Float16*)w->ln2_g;
   ps.ln2_b = (const _Float16*)w->ln2_b;
+  ps.qkv_w = (const _Float16*)w->qkv_w;
+  ps.qkv_b = (const _Float16*)w->qkv_b;
   hipLaunchKernelGGL(k_post_pack_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ps, (uint4*)pack, L);
 }
 
@@ -212,7 +239,7 @@ __device__ __forceinline__ void run_step(FragOf frag_of, uint32_t sa, Body&& bod
 
 
 // DBG: clock stamps per wave into a.dbg.  ABL (experiments build; results wrong): 1 = no LDS-DMA in the MLP
-// steps, 2 = no GELU, 8 = no MFMAs in the MLP steps.
+// steps, 2 = no GELU, 8 = no MFMAs in the MLP steps, 4 = QKV phase on accumulator-half (builtin) MFMAs.
 template <int DBG, int ABL>
 __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_block(const rf_post_args a) {
   constexpr int KS = HID / 16;   // 24
@@ -234,6 +261,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   // fragments of the pack; piece p of wave w = fragment 12 w + p.  The source is a wave-uniform pointer
   // (scalar registers) + the lane's 16 bytes.  Pieces past the last step are issued all the same (the counted
   // waits assume 12 per step): they re-read step 0 into a slot nobody reads any more.
+  const int n_steps = a.qkv_out ? PB_STEPS + PB_STEPS_C : PB_STEPS;   // with or without the next layer's QKV projection
   const char* const ring_src = (const char*)a.pack + ((size_t)16 + (size_t)wave * PB_PW) * 1024;
   const uint32_t lane_off = (uint32_t)lane * 16u;
   // (inline asm: hipcc's builtin took the source as a per-lane 64-bit address -- one v_lshl_add_u64 per piece in
@@ -244,7 +272,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
                  :: "s"(dst_step + (uint32_t)p * 1024u), "v"(lane_off), "s"(src_step + (size_t)p * 1024) : "memory");
   };
   auto step_src = [&](int S) __attribute__((always_inline)) {
-    return ring_src + (size_t)(S < PB_STEPS ? S : 0) * (PB_FRAGS * 1024);
+    return ring_src + (size_t)(S < n_steps ? S : 0) * (PB_FRAGS * 1024);
   };
   const uint32_t slots_s = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)slots;   // LDS byte address
   auto step_dst = [&](int S) __attribute__((always_inline)) {
@@ -418,12 +446,20 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   GeluTmp gt;
   const uint32_t bias_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)b1_l + (uint32_t)h * 16u;
   // step i: FFN2 of block i - 2 (F2), FFN1 of block i (F1), GELU of block i - 1 (GE); PAR = i & 1
-  auto mlp_step = [&](auto f2c, auto f1c, auto gec, auto parc, int i) __attribute__((always_inline)) {
+  // extra_c: what the previous step issued besides its 12 pieces; qb_c: this step also brings the next layer's QKV bias
+  // into the (now idle) FFN1-bias block -- every wave two pieces (`wave` and 4: the fifth is written four times over)
+  auto mlp_step = [&](auto f2c, auto f1c, auto gec, auto parc, int i, auto extra_c, auto qb_c) __attribute__((always_inline)) {
     constexpr bool F2 = decltype(f2c)::value, F1 = decltype(f1c)::value, GE = decltype(gec)::value && !(ABL & 2);
     constexpr int PAR = decltype(parc)::value;
     constexpr int NM = (F2 ? 24 : 0) + (F1 ? 24 : 0);    // MFMAs (= gaps) of the step
     const int S = PB_STEPS_A + i;
-    sync_step(std::integral_constant<int, 0>{});
+    sync_step(extra_c);
+    if constexpr (decltype(qb_c)::value) {
+      const char* const qb = (const char*)a.pack + ((size_t)16 + PB_RING_FRAGS) * 1024;
+      const uint32_t b1_s = slots_s + (uint32_t)(PB_SLOTS * PB_FRAGS * 1024);
+      issue_piece(qb + (size_t)wave * 1024, b1_s + (uint32_t)wave * 1024u, 0);
+      issue_piece(qb + 4 * 1024, b1_s + 4u * 1024u, 0);
+    }
     const uint32_t sa = slots_a + (uint32_t)((S % PB_SLOTS) * PB_FRAGS * 1024);
     const char* const nsrc = step_src(S + 2);
     const uint32_t ndst = step_dst(S + 2);
@@ -484,15 +520,17 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   using F_ = std::false_type;
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-  mlp_step(F_{}, T_{}, F_{}, P0{}, 0);
-  mlp_step(F_{}, T_{}, T_{}, P1{}, 1);
+  using E0 = std::integral_constant<int, 0>;
+  using E2 = std::integral_constant<int, 2>;
+  mlp_step(F_{}, T_{}, F_{}, P0{}, 0, E0{}, F_{});
+  mlp_step(F_{}, T_{}, T_{}, P1{}, 1, E0{}, F_{});
 #pragma unroll 1
   for (int i = 2; i < 48; i += 2) {
-    mlp_step(T_{}, T_{}, T_{}, P0{}, i);
-    mlp_step(T_{}, T_{}, T_{}, P1{}, i + 1);
+    mlp_step(T_{}, T_{}, T_{}, P0{}, i, E0{}, F_{});
+    mlp_step(T_{}, T_{}, T_{}, P1{}, i + 1, E0{}, F_{});
   }
-  mlp_step(T_{}, F_{}, T_{}, P0{}, 48);
-  mlp_step(T_{}, F_{}, F_{}, P1{}, 49);
+  mlp_step(T_{}, F_{}, T_{}, P0{}, 48, E0{}, T_{});
+  mlp_step(T_{}, F_{}, F_{}, P1{}, 49, E2{}, F_{});
   static_for<0, KS>([&](auto Kc) __attribute__((always_inline)) {   // + y (the fp16 operands still in registers)
     constexpr int kk = decltype(Kc)::value;
     acc[kk >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(id_perm[kk & 1], __builtin_bit_cast(half8, xf[kk]), acc[kk >> 1], 0, 0, 0);
@@ -530,7 +568,95 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
         *(uint4*)(dst + (size_t)(2 * fb) * 512) = make_uint4(sx0[0], sy0[0], sx0[1], sy0[1]);
         *(uint4*)(dst + (size_t)(2 * fb + 1) * 512) = make_uint4(sx1[0], sy1[0], sx1[1], sy1[1]);
       }
+      // ... and as the accumulator left them they are the B operands of the next layer's QKV projection
+      xf[2 * fb] = rf_u32x4{pk[0].x, pk[0].y, pk[1].x, pk[1].y};
+      xf[2 * fb + 1] = rf_u32x4{pk[2].x, pk[2].y, pk[3].x, pk[3].y};
     });
+  }
+  const uint64_t ts_c = DBG ? __builtin_amdgcn_s_memtime() : 0;
+
+  // ---- phase C: Q | K | V of the NEXT layer = x' Wqkv^T + b, 36 blocks of 32 features, two per ring step --------
+  // The same loop shape as FFN1 (vector-register accumulators through inline-asm MFMAs, the two blocks' chains
+  // alternating, bias as the accumulator input); the fp16 conversion, half exchange and the two 16-byte stores of
+  // the previous step's blocks ride in the MFMA gaps.  Stores are unconditional (the buffers are padded to whole
+  // tiles, nobody reads rows past the token count): exactly four per step, which the counted waits rely on.
+  if (a.qkv_out) {
+    f32x16 qa[2][2];   // [step parity][block of the step]
+    _Float16* const qdst = a.qkv_out + (tb * (3 * KS) * 64 + lane) * 8;
+    uint32_t pkw[8];
+    uint32_t sw[4];
+    auto epi_slot = [&](auto Oc, const f32x16 (&src)[2], int blk0) __attribute__((always_inline)) {
+      constexpr int O = decltype(Oc)::value, b = O / 14, w = O % 14;   // 28 slots: 2 blocks x (8 conversions, 4 exchanges, 2 stores)
+      if constexpr (w < 8) {
+        const half2v o = {(_Float16)src[b][2 * w], (_Float16)src[b][2 * w + 1]};
+        pkw[w] = __builtin_bit_cast(uint32_t, o);
+      } else if constexpr (w < 12) {
+        constexpr int m = (w - 8) >> 1, c = (w - 8) & 1;
+        const auto sx = __builtin_amdgcn_permlane32_swap(pkw[4 * m + c], pkw[4 * m + 2 + c], false, false);
+        sw[2 * c] = sx[0];
+        sw[2 * c + 1] = sx[1];
+        if constexpr (c == 1) {   // both words of the pair exchanged: fragment 2 (blk0 + b) + m, lane-linear
+          // (non-temporal stores measured no better: 65 k against 53-62 k cycles for the phase)
+          *(uint4*)(qdst + (size_t)(2 * (blk0 + b) + m) * 512) = make_uint4(sw[0], sw[2], sw[1], sw[3]);
+        }
+      }
+    };
+    auto qkv_step = [&](auto epic, auto parc, int t) __attribute__((always_inline)) {
+      constexpr bool EPI = decltype(epic)::value;     // the previous step's blocks are finished under this step's MFMAs
+      constexpr int PAR = decltype(parc)::value;
+      const int S = PB_STEPS + t;
+      if (t >= 2 && !(ABL & 2)) sync_step(std::integral_constant<int, 4>{});
+      else sync_step(E0{});
+      const uint32_t sa = slots_a + (uint32_t)((S % PB_SLOTS) * PB_FRAGS * 1024);
+      const char* const nsrc = step_src(S + 2);
+      const uint32_t ndst = step_dst(S + 2);
+      f32x4v bq[2][4];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const uint32_t ba = bias_a + (uint32_t)(2 * t + b) * 128u;
+        asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(bq[b][0]) : "v"(ba));
+        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(bq[b][1]) : "v"(ba));
+        asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(bq[b][2]) : "v"(ba));
+        asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(bq[b][3]) : "v"(ba));
+      }
+      run_step<PB_FRAGS>([](int m) constexpr { return m; }, sa, [&](auto Mc, const rf_u32x4& afr) __attribute__((always_inline)) {
+        constexpr int m = decltype(Mc)::value, b = m & 1, kk = m >> 1;
+        if constexpr (m == 0)
+          asm volatile("" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[1][2]), "+v"(bq[1][3]));
+        if constexpr (kk == 0) {
+          f32x16 b0 = {bq[b][0][0], bq[b][0][1], bq[b][0][2], bq[b][0][3], bq[b][1][0], bq[b][1][1], bq[b][1][2], bq[b][1][3],
+                       bq[b][2][0], bq[b][2][1], bq[b][2][2], bq[b][2][3], bq[b][3][0], bq[b][3][1], bq[b][3][2], bq[b][3][3]};
+          if constexpr (ABL & 4) {
+            qa[PAR][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, afr), __builtin_bit_cast(half8, xf[kk]), b0, 0, 0, 0);
+          } else {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(b0) : "v"(afr), "v"(xf[kk]));
+            qa[PAR][b] = b0;
+          }
+        } else {
+          if constexpr (ABL & 4)
+            qa[PAR][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, afr), __builtin_bit_cast(half8, xf[kk]), qa[PAR][b], 0, 0, 0);
+          else
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(qa[PAR][b]) : "v"(afr), "v"(xf[kk]));
+        }
+        if constexpr (EPI && !(ABL & 2)) {
+          constexpr int o0 = m * 28 / PB_FRAGS, o1 = (m + 1) * 28 / PB_FRAGS;
+          static_for<o0, o1>([&](auto Oc) __attribute__((always_inline)) { epi_slot(Oc, qa[PAR ^ 1], 2 * t - 2); });
+        }
+        if constexpr ((m & 3) == 3) issue_piece(nsrc, ndst, m >> 2);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    qkv_step(F_{}, P0{}, 0);
+    qkv_step(T_{}, P1{}, 1);
+#pragma unroll 1
+    for (int t = 2; t < PB_STEPS_C; t += 2) {
+      qkv_step(T_{}, P0{}, t);
+      qkv_step(T_{}, P1{}, t + 1);
+    }
+    // the last step's blocks: the MFMA results are read by the vector ALU right away -- the XDL write hazard is padded by hand
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(qa[1][0]), "+v"(qa[1][1]));
+    static_for<0, 28>([&](auto Oc) __attribute__((always_inline)) { epi_slot(Oc, qa[1], 2 * PB_STEPS_C - 2); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   if (DBG && a.dbg && lane == 0 && blockIdx.x < 512) {   // the buffer holds 4096 waves x 8 floats
     float* d = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -540,17 +666,25 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
     d[2] = (float)(ts_ln1 - ts_a);       // out-projection (6 steps + residual)
     d[3] = (float)(ts_b - ts_ln1);       // LayerNorm 1
     d[4] = (float)(ts_ln2 - ts_b);       // MLP (50 steps + residual)
-    d[5] = (float)(te - ts_ln2);         // LayerNorm 2 + stores
+    d[5] = (float)(ts_c - ts_ln2);       // LayerNorm 2 + stores
     d[6] = (float)t_wait;                // vmcnt wait + barrier, all 56 steps
     d[7] = (float)(__builtin_amdgcn_s_memrealtime() - tr_entry);   // 100-MHz ticks, whole wave
     float* d2 = d + 4 * 8;               // the rows of waves 4-7 (the workgroup has four): out-projection step by step
     d2[0] = (float)(ts_step[0] - ts_a);
     for (int q = 1; q < PB_STEPS_A; ++q) d2[q] = (float)(ts_step[q] - ts_step[q - 1]);
     d2[6] = (float)(ts_ln1 - ts_step[PB_STEPS_A - 1]);   // residual MFMAs
+    d2[7] = (float)(te - ts_c);                          // the next layer's QKV projection (18 steps)
   }
 }
 
-int rf_launch_post_block(const rf_post_args& a, int token_slots, hipStream_t st) {
+int rf_launch_post_block(const rf_post_args& a_in, int token_slots, hipStream_t st) {
+  rf_post_args a = a_in;
+#ifdef RF_EXPERIMENTS
+  if (a.abl & 32) {   // stamps of the launches WITH the QKV phase only (the last layer's launch has none and would overwrite them)
+    if (!a.qkv_out) a.dbg = nullptr;
+    a.abl &= ~32;
+  }
+#endif
   const dim3 grid((token_slots + PB_TOK - 1) / PB_TOK), block(PB_WAVES * 64);
   const size_t lds = PB_LDS_BYTES;
 #define RF_PB_LAUNCH(D, A)                                                  \
@@ -567,6 +701,7 @@ int rf_launch_post_block(const rf_post_args& a, int token_slots, hipStream_t st)
       case 2: RF_PB_LAUNCH(1, 2);
       case 3: RF_PB_LAUNCH(1, 3);
       case 8: RF_PB_LAUNCH(1, 8);
+      case 4: RF_PB_LAUNCH(1, 4);
       default: RF_PB_LAUNCH(1, 0);
     }
   }

@@ -66,6 +66,7 @@ RF_KNOB(rf_knob_debug_epi, 1)          // encoder: which kernel writes clock sta
 RF_KNOB(rf_knob_att_heads, 1)          // encoder: heads per attention workgroup (1 | 2)
 RF_KNOB(rf_knob_one_query, 1)          // encoder: a single sequence of <= 32 tokens takes the fused QKV + attention launch
 RF_KNOB(rf_knob_post_block, 1)         // encoder: out-projection + MLP of a layer as one launch at >= 8192 token slots (encoder_post.hip)
+RF_KNOB(rf_knob_post_qkv, 1)           // encoder: k_post_block also computes the next layer's QKV projection
 RF_KNOB(rf_knob_post_dbg, 0)           // encoder: k_post_block ablation bits (results wrong)
 RF_KNOB(rf_knob_gemm_tile_dma, 0)      // encoder: k_gemm_tile LDS-DMA issue: 0 = halves take turns, 8 pieces in a burst (product); 1 = every wave 4 pieces between its MFMAs; 2 = none (ablation)
 #undef RF_KNOB

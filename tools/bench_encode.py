@@ -94,7 +94,7 @@ def main():
             okx = ex[..., 0] > 0
             if okx.any():
                 print("out-projection step by step (cycles, medians): " + " ".join("%.0f" % np.median(ex[..., q][okx]) for q in range(6)) +
-                      "; residual MFMAs %.0f" % np.median(ex[..., 6][okx]))
+                      "; residual MFMAs %.0f; next layer's QKV (18 steps) %.0f" % (np.median(ex[..., 6][okx]), np.median(ex[..., 7][okx])))
             ok = st[..., 0] > 0
             for name, sel in (("all workgroups", slice(0, 512)), ("workgroups 0-255 (first on their CU)", slice(0, 256)),
                               ("workgroups 256-511", slice(256, 512))):

@@ -229,10 +229,12 @@ __device__ __forceinline__ void run_step(FragOf frag_of, uint32_t sa, Body&& bod
   static_for<0, (NP < 3 ? NP : 3)>([&](auto Gc) __attribute__((always_inline)) { read_pair(Gc); });
   static_for<0, NP>([&](auto Gc) __attribute__((always_inline)) {
     constexpr int G = decltype(Gc)::value;
-    if constexpr (G + 3 < NP) read_pair(std::integral_constant<int, G + 3>{});
-    constexpr int newer = (NP - 1 - G) < 3 ? (NP - 1 - G) : 3;   // pairs read after pair G
+    // pair G + 3 is read BEHIND the pair's first MFMA (its two issue slots sit in that MFMA's shadow, not in front
+    // of it together with the previous gap's vector work and LDS-DMA piece): pairs read after pair G at its wait = 2
+    constexpr int newer = (NP - 1 - G) < 2 ? (NP - 1 - G) : 2;
     lds_wait_pair<2 * newer>(fa[G & 3]);
     body(std::integral_constant<int, 2 * G>{}, fa[G & 3][0]);
+    if constexpr (G + 3 < NP) read_pair(std::integral_constant<int, G + 3>{});
     body(std::integral_constant<int, 2 * G + 1>{}, fa[G & 3][1]);
   });
 }

@@ -139,6 +139,47 @@ def pipelined(enqueue, n_lanes, steps, warm, sync):
     return (time.perf_counter() - t0) / steps
 
 
+def gather_expected(local_scores, local_ids, world, k, cdev):
+    """N > 1 answer check, shared by the headline job and the weak job: every rank contributes the
+    reference top-k lists of ITS shard for the first nq queries (float64 scores, GLOBAL int64 ids),
+    ONE all-gather each, and the lists are merged by (score desc, id asc) -- what a reference over the
+    whole corpus returns.  COLLECTIVE; -> (scores [nq, k] float64, ids [nq, k] int64) on every rank."""
+    import torch
+    import torch.distributed as dist
+    from oracle import search as osearch
+    nq = int(local_scores.shape[0])
+    t_s = torch.as_tensor(np.ascontiguousarray(local_scores, dtype=np.float64)).to(cdev).contiguous()
+    t_i = torch.as_tensor(np.ascontiguousarray(local_ids, dtype=np.int64)).to(cdev).contiguous()
+    all_s = torch.empty((world * nq, k), dtype=torch.float64, device=cdev)
+    all_i = torch.empty((world * nq, k), dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(all_s, t_s)
+    dist.all_gather_into_tensor(all_i, t_i)
+    return osearch.merge_shards(all_s.cpu().numpy().reshape(world, nq, k), all_i.cpu().numpy().reshape(world, nq, k), k)
+
+
+def compare_global(got_scores, got_ids, exp_s, exp_i, k):
+    """The merged answer of the sharded step (float32 scores, int64 global ids of the first nq queries)
+    against gather_expected's lists -> the global_* fields of the JSON line."""
+    nq = int(exp_i.shape[0])
+    got_i = np.asarray(got_ids)[:nq]
+    got_s = np.asarray(got_scores)[:nq].astype(np.float64)
+    return {"global_ids_ranks_exact": bool(np.array_equal(got_i, exp_i)),
+            "global_recall_at_10": float(np.mean([len(set(got_i[b]) & set(exp_i[b])) / k for b in range(nq)])),
+            "global_max_abs_score_err": float(np.abs(got_s - exp_s.astype(np.float32).astype(np.float64)).max()),
+            "global_checked_queries": nq}
+
+
+def all_ranks_agree(flag: bool, world, cdev) -> bool:
+    """AND of a per-rank boolean over the job (MIN all-reduce).  COLLECTIVE when world > 1."""
+    if world <= 1:
+        return bool(flag)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def main():
     args = parse()
     # stdout carries ONE line, the JSON: everything any library prints to fd 1 before that (RCCL's
@@ -320,10 +361,7 @@ def main():
             clean = all(int(r[2].abs().sum().item()) == 0 for r in done) and \
                 all(torch.equal(r[1], done[0][1]) for r in done)
             res = done[-1]
-        if world > 1:
-            t = torch.tensor([1 if clean else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            clean = bool(int(t.item()))
+        clean = all_ranks_agree(clean, world, dev)
         return dict(index=index, q=q, searcher=searcher, lanes=lanes, serial_s=serial_s, elapsed=elapsed,
                     n_lanes=n_lanes, flags_clean=clean, res=res, bare=bare, label=label)
 
@@ -334,22 +372,10 @@ def main():
         from oracle import c_oracle
         os_l, oi_l = c_oracle.search(q16[:nq], c16_local, k)
         cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        t_s = torch.from_numpy(np.ascontiguousarray(os_l, dtype=np.float64)).to(cdev)
-        t_i = torch.from_numpy(np.ascontiguousarray(oi_l, dtype=np.int64) + row_base).to(cdev)
-        all_s = torch.empty((world * nq, k), dtype=torch.float64, device=cdev)
-        all_i = torch.empty((world * nq, k), dtype=torch.int64, device=cdev)
-        dist.all_gather_into_tensor(all_s, t_s.contiguous())
-        dist.all_gather_into_tensor(all_i, t_i.contiguous())
+        exp_s, exp_i = gather_expected(os_l, np.asarray(oi_l, dtype=np.int64) + row_base, world, k, cdev)
         if rank != 0 or job["res"] is None:
             return {}
-        exp_s, exp_i = osearch.merge_shards(all_s.cpu().numpy().reshape(world, nq, k),
-                                            all_i.cpu().numpy().reshape(world, nq, k), k)
-        got_i = job["res"][1][:nq].cpu().numpy()
-        got_s = job["res"][0][:nq].cpu().numpy().astype(np.float64)
-        return {"global_ids_ranks_exact": bool(np.array_equal(got_i, exp_i)),
-                "global_recall_at_10": float(np.mean([len(set(got_i[b]) & set(exp_i[b])) / k for b in range(nq)])),
-                "global_max_abs_score_err": float(np.abs(got_s - exp_s.astype(np.float32).astype(np.float64)).max()),
-                "global_checked_queries": nq}
+        return compare_global(job["res"][0].cpu().numpy(), job["res"][1].cpu().numpy(), exp_s, exp_i, k)
 
     # ---- the headline job ---------------------------------------------------------------------
     if args.scaling == "strong" and world > 1:
@@ -644,6 +670,7 @@ def config4(args, dev, index1m, lanes, c16_1m, k):
         torch.cuda.synchronize()
         t_txt.append(time.perf_counter() - t)
     txt_s = float(np.median(t_txt))
+    host_stages = {k_: (round(v, 5) if isinstance(v, float) else v) for k_, v in getattr(emb, "ingest_stats", {}).items()}
     # search over the 10 k corpus: 64 unseen chunk texts as queries
     ix = GpuIndex(384, n, dev)
     ix.add(vec)
@@ -662,7 +689,10 @@ def config4(args, dev, index1m, lanes, c16_1m, k):
            "encode_s": round(enc_s, 5), "batches": len(batches), "steps": len(t_ids),
            "from_text": {"texts_per_s": round(n / txt_s, 1), "tokens_per_s": round(tokens / txt_s, 1),
                          "text_to_embedding_s": round(txt_s, 5), "host_threads": len(os.sched_getaffinity(0)),
-                         "what": "native WordPiece tokenizer + chunked pinned uploads + bucketed encode"},
+                         "what": "native WordPiece tokenizer + chunked pinned uploads + bucketed encode",
+                         "host_stage_s": host_stages,
+                         "host_stage_note": "host seconds of the last run per stage (the GPU work is only enqueued); "
+                                            "their sum against text_to_embedding_s says how much of the ingest the host serialises"},
            "search_batch64_ms": round(search_ms, 5),
            "end_to_end_embed_plus_search_s": round(txt_s + search_ms * 1e-3, 5),
            "roofline": {"bound": "mfma", "kernel": "rf_encode (all kernels of the forward)",
@@ -721,13 +751,9 @@ def weak_job(args, dev, rank, world, run_job, k):
     ix, q = job["index"], job["q"]
     s_, i_, e_ = ix.search_exhaustive(q[:nq].contiguous(), k, id_base=rank * rows, want_exact=True)
     cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
-    all_s = torch.empty((world * nq, k), dtype=torch.float64, device=cdev)
-    all_i = torch.empty((world * nq, k), dtype=torch.int64, device=cdev)
-    dist.all_gather_into_tensor(all_s, e_.to(cdev).contiguous())
-    dist.all_gather_into_tensor(all_i, i_.to(cdev).contiguous())
+    exp_s, exp_i = gather_expected(e_.cpu().numpy(), i_.cpu().numpy(), world, k, cdev)
     if rank != 0:
         return None
-    exp_s, exp_i = osearch.merge_shards(all_s.cpu().numpy().reshape(world, nq, k), all_i.cpu().numpy().reshape(world, nq, k), k)
     got_i = job["res"][1][:nq].cpu().numpy()
     stages = [ix.search_profile(q, k) for _ in range(20)]
     emit_ms = float(np.mean([s["emit"] for s in stages]))

@@ -152,6 +152,14 @@ size_t rf_packed_shard_words(int B, int k);
 int rf_merge_shards_packed(const int64_t* packed_dev, int W, int B, int k,
                            float* scores_out_dev, int64_t* ids_out_dev,
                            uint32_t* flags_out_dev, void* stream);
+/* Shards that are not contiguous in the global row numbering (a store that grows by appending a
+ * slice of every insert to every rank): rf_search runs with id_base 0 and this call turns the
+ * LOCAL row numbers it wrote into global ids through the shard's table, in place, on `stream`:
+ * ids_dev[i] = id_map_dev[ids_dev[i]] for ids >= 0 (-1 = "no hit" stays; a row number past n_map
+ * becomes -1).  Between the scan and the all-gather: the N > 1 step is then four enqueues
+ * (rf_search, rf_map_ids, ncclAllGather, rf_merge_shards_packed) and no host library touches
+ * the ids.  New in this build; stands beside vector_rag_mcp/main.py:51-57. */
+int rf_map_ids(int64_t* ids_dev, int64_t n, const int64_t* id_map_dev, int64_t n_map, void* stream);
 /* Test hook: raw MFMA scan scores fp32 [B, n] for the first n rows. */
 int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,
                     float* out_dev, void* stream);

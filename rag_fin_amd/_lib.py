@@ -69,6 +69,7 @@ SIGNATURES = {
                                 c_void_p]),
     "rf_packed_shard_words": (c_size_t, [c_int, c_int]),
     "rf_merge_shards_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rf_map_ids": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "rf_tokenizer_create": (c_int, [POINTER(c_void_p), c_char_p, c_size_t, c_int, c_int]),
     "rf_tokenizer_destroy": (c_int, [c_void_p]),
     "rf_tokenizer_set_punctuation": (c_int, [c_void_p, c_void_p, c_int]),

@@ -67,12 +67,38 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _object_digest(src: str, headers: list[str], flags: list[str]) -> str:
+    """What an object file was compiled from: the flags, the source and every header (content, not mtime: a
+    tree synced with preserved mtimes, or an edit of FLAGS, must recompile too)."""
+    h = hashlib.sha256()
+    h.update(" ".join(flags).encode())
+    for path in [src] + headers:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build_lib(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
+    # one builder at a time per tree: under torch.distributed.run every rank that finds a stale library would
+    # otherwise write the same .o / .so files concurrently
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_lib_locked(force, verbose, experiments)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_lib_locked(force: bool, verbose: bool, experiments: bool) -> str:
     hipcc = _hipcc()
     headers = _headers()
     suffix = ".exp.o" if experiments else ".o"
     flags = FLAGS + (["-DRF_EXPERIMENTS"] if experiments else [])
     out = EXP_LIB_PATH if experiments else LIB_PATH
+    if not force and os.path.exists(out) and built_digest(out) == source_digest(experiments):
+        return out   # another process built it while this one waited for the lock
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     objs = [os.path.splitext(s)[0] + suffix for s in srcs]
 
@@ -85,10 +111,18 @@ def build_lib(force: bool = False, verbose: bool = False, experiments: bool = Fa
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
+    rebuilt = []
+
     def compile_one(pair):
         src, obj = pair
-        if force or _stale(obj, [src] + headers):
+        want = _object_digest(src, headers, flags)
+        side = obj + ".id"
+        have = open(side).read().strip() if os.path.exists(side) else ""
+        if force or not os.path.exists(obj) or have != want:
             run([hipcc, *flags, "-c", src, "-o", obj])
+            with open(side, "w") as f:
+                f.write(want)
+            rebuilt.append(obj)
 
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
@@ -97,7 +131,7 @@ def build_lib(force: bool = False, verbose: bool = False, experiments: bool = Fa
     id_obj = os.path.join(CSRC, "build_id" + suffix)
     id_txt = id_obj + ".id"
     have = open(id_txt).read().strip() if os.path.exists(id_txt) else ""
-    relink = force or _stale(out, objs)
+    relink = force or bool(rebuilt) or _stale(out, objs)
     if have != digest or not os.path.exists(id_obj):
         run([hipcc, *flags, f'-DRF_BUILD_ID="{digest}"', "-c", os.path.join(CSRC, "build_id.cpp"), "-o", id_obj])
         with open(id_txt, "w") as f:

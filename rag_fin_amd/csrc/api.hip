@@ -283,6 +283,27 @@ extern "C" int rf_merge_shards_packed(const int64_t* packed_dev, int W, int B, i
                                 (hipStream_t)stream);
 }
 
+// local row numbers -> global ids through a table, in place (-1 = "no hit" stays -1)
+__global__ void __launch_bounds__(256) k_map_ids(int64_t* __restrict__ ids, int64_t n, const int64_t* __restrict__ id_map,
+                                                 int64_t n_map) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = ids[i];
+  if (v >= 0) ids[i] = v < n_map ? id_map[v] : (int64_t)-1;
+}
+
+extern "C" int rf_map_ids(int64_t* ids_dev, int64_t n, const int64_t* id_map_dev, int64_t n_map, void* stream) {
+  if (!ids_dev || n < 0 || n_map < 0 || (n_map > 0 && !id_map_dev)) {
+    rf_set_error("rf_map_ids: bad argument");
+    return RF_ERR_INVALID;
+  }
+  if (n == 0) return RF_OK;
+  hipLaunchKernelGGL(k_map_ids, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids_dev, n,
+                     id_map_dev, n_map);
+  RF_HIP(hipGetLastError());
+  return RF_OK;
+}
+
 extern "C" int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,
                                float* out_dev, void* stream) {
   if (!ix || !q_dev || !out_dev || B <= 0 || n <= 0 || n > ix->size) {

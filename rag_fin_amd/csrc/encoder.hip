@@ -52,8 +52,10 @@ struct rf_encoder {
     int tuning_gen;        // rf_set_tuning generation the graph was captured under
     hipGraphExec_t exec;   // nullptr: seen once (the plain run also sets the kernels' attributes)
     bool dead;             // capture failed for this key: stay on plain launches
+    hipEvent_t done;       // recorded behind the last launch of exec: an evicted exec is destroyed only once it has run
   };
-  mutable std::vector<Graph> graphs;
+  mutable std::vector<Graph> graphs;            // least recently used first
+  mutable std::vector<Graph> retired;           // evicted while their last launch may still be in flight
   mutable hipStream_t cap_stream = nullptr;
   mutable std::mutex mu;
 };
@@ -133,8 +135,11 @@ extern "C" int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cf
 
 extern "C" int rf_encoder_destroy(rf_encoder_t* enc) {
   if (enc) {
-    for (auto& g : enc->graphs)
-      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto* v : {&enc->graphs, &enc->retired})
+      for (auto& g : *v) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.done) (void)hipEventDestroy(g.done);
+      }
     if (enc->cap_stream) (void)hipStreamDestroy(enc->cap_stream);
   }
   delete enc;
@@ -1916,27 +1921,50 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
 static int encode_graphed(const rf_encoder_t* enc, const int32_t* ids, const int32_t* lens, int B, int T, void* o16,
                           float* o32, void* wsp, hipStream_t st) {
   std::lock_guard<std::mutex> lock(enc->mu);
+  // an exec leaves the cache through `retired`: destroyed once the event behind its last launch has fired
+  // (hipGraphExecDestroy on an exec that is still running on another stream is undefined)
+  auto retire = [&](rf_encoder::Graph& e) {
+    if (e.exec) enc->retired.push_back(e);
+    else if (e.done) (void)hipEventDestroy(e.done);
+  };
+  for (size_t i = 0; i < enc->retired.size();) {
+    rf_encoder::Graph& r = enc->retired[i];
+    if (!r.done || hipEventQuery(r.done) == hipSuccess) {
+      (void)hipGraphExecDestroy(r.exec);
+      if (r.done) (void)hipEventDestroy(r.done);
+      enc->retired.erase(enc->retired.begin() + i);
+    } else {
+      ++i;
+    }
+  }
+  (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is not an error of this call
   // graphs captured under other tuning settings (rf_set_tuning picks kernels) are dropped
   for (size_t i = 0; i < enc->graphs.size();) {
     if (enc->graphs[i].tuning_gen != rf_tuning_generation) {
-      if (enc->graphs[i].exec) (void)hipGraphExecDestroy(enc->graphs[i].exec);
+      retire(enc->graphs[i]);
       enc->graphs.erase(enc->graphs.begin() + i);
     } else {
       ++i;
     }
   }
   rf_encoder::Graph* g = nullptr;
-  for (auto& e : enc->graphs)
+  for (size_t i = 0; i < enc->graphs.size(); ++i) {
+    auto& e = enc->graphs[i];
     if (e.B == B && e.T == T && e.ids == ids && e.lens == lens && e.o16 == o16 && e.o32 == (void*)o32 && e.ws == wsp) {
-      g = &e;
+      // least recently used first: a hit moves to the back
+      rf_encoder::Graph hit = e;
+      enc->graphs.erase(enc->graphs.begin() + i);
+      enc->graphs.push_back(hit);
+      g = &enc->graphs.back();
       break;
     }
+  }
   if (!g) {
-    if (enc->graphs.size() >= 32) {   // evict the oldest
-      if (enc->graphs.front().exec) (void)hipGraphExecDestroy(enc->graphs.front().exec);
+    if (enc->graphs.size() >= 32) {   // evict the least recently used
+      retire(enc->graphs.front());
       enc->graphs.erase(enc->graphs.begin());
     }
-    enc->graphs.push_back(rf_encoder::Graph{B, T, ids, lens, o16, (void*)o32, wsp, rf_tuning_generation, nullptr, false});
+    enc->graphs.push_back(rf_encoder::Graph{B, T, ids, lens, o16, (void*)o32, wsp, rf_tuning_generation, nullptr, false, nullptr});
     return RF_ERR_UNSUPPORTED;
   }
   if (g->dead) return RF_ERR_UNSUPPORTED;
@@ -1964,6 +1992,8 @@ static int encode_graphed(const rf_encoder_t* enc, const int32_t* ids, const int
     g->exec = exec;
   }
   RF_HIP(hipGraphLaunch(g->exec, st));
+  if (!g->done && hipEventCreateWithFlags(&g->done, hipEventDisableTiming) != hipSuccess) g->done = nullptr;
+  if (g->done) RF_HIP(hipEventRecord(g->done, st));
   return RF_OK;
 }
 

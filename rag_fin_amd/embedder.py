@@ -212,7 +212,17 @@ class Embedder:
         cur = torch.cuda.current_stream(self.device)
         if self._small_done is not None:
             cur.wait_event(self._small_done)     # a previous caller on ANOTHER stream may still be using the buffers
-        sb["ids"][:B * T].copy_(ids.reshape(-1), non_blocking=True)
+        # rf_encode keys its cached hipGraphs on (B, T, buffers) and the tokenizer returns T = the longest row, so every
+        # query length would be a key of its own: round the width up to a multiple of 32 (padding changes no bit:
+        # tests/test_encoder_gpu.py::test_padding_content_and_width_are_ignored) -- at most 8 widths per batch size
+        Tr = min((T + 31) // 32 * 32, self.cfg["max_position"])
+        if Tr != T and B * Tr <= self.SMALL_SLOTS:
+            wide = sb["ids"][:B * Tr].view(B, Tr)
+            wide[:, :T].copy_(ids, non_blocking=True)
+            wide[:, T:].zero_()
+            T = Tr
+        else:
+            sb["ids"][:B * T].copy_(ids.reshape(-1), non_blocking=True)
         sb["lens"][:B].copy_(lens, non_blocking=True)
         ids, lens = sb["ids"], sb["lens"]
         out16 = None if want32 else sb["o16"]
@@ -263,19 +273,35 @@ class Embedder:
         # a tokenizer object without batch_native (a test double) takes the per-sentence path.
         # Large inputs go in chunks of `chunk_texts`: rf_encode only ENQUEUES, so while the GPU works
         # through one chunk's buckets the host is already tokenising the next chunk.
+        import time
         sentences = list(sentences)
         n = len(sentences)
         out = torch.empty((n, self.dim), dtype=odt, device=self.device)
         if n == 0:
             return out
+        # host seconds per stage of the last call (bench.py reports them beside from_text): the GPU work is only
+        # ENQUEUED below, so whatever the host spends here in series is time the card may sit idle
+        stats = self.ingest_stats = {"prepass_s": 0.0, "native_tokenize_s": 0.0, "sort_s": 0.0, "pinned_wait_s": 0.0, "pinned_stage_s": 0.0,
+                                     "upload_enqueue_s": 0.0, "bucket_and_launch_s": 0.0, "chunks": 0, "buckets": 0}
+
+        def lap(key, t0):
+            t1 = time.perf_counter()
+            stats[key] += t1 - t0
+            return t1
         chunk_texts = 4096
         # the first chunk is a quarter of the others: nothing overlaps ITS tokenisation, so the
         # GPU should get its first buckets early
         starts = [0] + list(range(min(n, chunk_texts // 4), n, chunk_texts))
         for ci, c0 in enumerate(starts):
             part = sentences[c0:(starts[ci + 1] if ci + 1 < len(starts) else n)]
+            stats["chunks"] += 1
+            tm = time.perf_counter()
             if hasattr(self.tokenizer, "batch_native"):
                 all_ids, all_lens = self.tokenizer.batch_native(part, self.max_seq_length)
+                lt = getattr(self.tokenizer, "last_timing", None)
+                if lt:
+                    stats["prepass_s"] += lt["prepass_s"]
+                    stats["native_tokenize_s"] += lt["native_s"]
             else:
                 rows = [self.tokenizer.encode(s, self.max_seq_length) for s in part]
                 all_lens = np.array([len(r) for r in rows], dtype=np.int32)
@@ -291,8 +317,10 @@ class Embedder:
             if not held[0]:      # pinned staging buffers + copy stream below are one-at-a-time
                 self._ingest_lock.acquire()
                 held[0] = True
+            tm = time.perf_counter()
             order = np.argsort(all_lens, kind="stable")
             sorted_lens = all_lens[order].astype(np.int64)
+            tm = lap("sort_s", tm)
             # ONE upload per chunk, from pinned memory on a side stream: a pageable host-to-device copy
             # on the compute stream would make the host wait for every kernel already queued there, and
             # the chunk-to-chunk overlap would be gone.  Buckets are then gathered ON the device.
@@ -311,9 +339,11 @@ class Embedder:
             pb = self._pin[ci & 1]
             if pb["done"] is not None:
                 pb["done"].synchronize()      # its previous upload has left the buffers
+            tm = lap("pinned_wait_s", tm)
             pb["ids"][:m * Tc].view(m, Tc).copy_(torch.from_numpy(all_ids))
             pb["lens"][:m].copy_(torch.from_numpy(all_lens))
             pb["order"][:m].copy_(torch.from_numpy(order.astype(np.int64)))
+            tm = lap("pinned_stage_s", tm)
             with torch.cuda.stream(self._copy_stream):
                 ids_dev = pb["ids"][:m * Tc].view(m, Tc).to(self.device, non_blocking=True)
                 lens_dev = pb["lens"][:m].to(self.device, non_blocking=True)
@@ -324,8 +354,10 @@ class Embedder:
             torch.cuda.current_stream(self.device).wait_event(ready)
             for t in (ids_dev, lens_dev, order_dev):
                 t.record_stream(torch.cuda.current_stream(self.device))
+            tm = lap("upload_enqueue_s", tm)
             i = 0
             while i < m:
+                stats["buckets"] += 1
                 # rows are sorted ascending, so the last row of a bucket sets its width and
                 # (rows in bucket) x (that width) is non-decreasing in the bucket's end: binary search
                 cost = (np.arange(1, m - i + 1, dtype=np.int64)) * sorted_lens[i:]
@@ -336,6 +368,7 @@ class Embedder:
                 lens = lens_dev.index_select(0, sel)
                 out.index_copy_(0, sel + c0, self.encode_ids(ids, lens, out_dtype=out_dtype))
                 i = j
+            lap("bucket_and_launch_s", tm)
         return out
 
     def encode(self, sentences, batch_size: int = 32, **_ignored) -> np.ndarray:

@@ -109,7 +109,11 @@ def main() -> None:
     get_rag()
     logger.info("Starting Vector RAG MCP Server on port %s (collection %s)", os.environ["PORT"],
                 COLLECTION_NAME)
-    mcp.run(transport="streamable-http")
+    try:
+        mcp.run(transport="streamable-http")
+    finally:   # release the ranks parked in start_workers(), however the server ends
+        if hasattr(rag.collection, "stop_workers"):
+            rag.collection.stop_workers()
 
 
 if __name__ == "__main__":

@@ -28,6 +28,12 @@ from ctypes import c_void_p
 from . import _lib
 
 
+# Flag bit a rank sends in place of an answer when its local scan raised (ShardedSearcher.poison_step):
+# the merge ORs the shards' flags, so EVERY rank sees it, nobody enters the resolution collective and
+# the leading rank raises instead of returning a partial answer.  (int32 view of 0x80000000.)
+SHARD_FAILED = -(1 << 31)
+
+
 class HipShardBackend:
     """Local scan = rf_search / rf_search_exhaustive, merge = rf_merge_shards* (all HIP)."""
 
@@ -119,7 +125,8 @@ class ShardedSearcher:
     # -- the step --------------------------------------------------------------------------------
     def search_on(self, q16, k: int, workspace, stream):
         """The step as three bare enqueues on `stream` (a torch.cuda.Stream of this rank's device):
-        rf_search -> ncclAllGather -> rf_merge_shards_packed, all through ctypes with cached
+        rf_search -> [rf_map_ids when the shard has an id table] -> ncclAllGather -> rf_merge_shards_packed,
+        all through ctypes with cached
         pointers -- no torch call on the hot path, no current-stream switch, no host sync.  Needs
         enable_direct_rccl() when world > 1.  q16 must be a contiguous fp16 [B, dim] tensor on the
         device that stays alive until the step has run.  Returns (scores, global ids, GLOBAL
@@ -130,6 +137,11 @@ class ShardedSearcher:
         st = self._lanes.get(key)
         if st is None:
             lane = self.backend.new_lane(B, k, self.world)
+            # new_lane zero-fills its send buffer on torch's CURRENT stream; the step below runs on `stream`.  Without
+            # this (one-time) wait the fill can land after rf_search has written the lane's first answer into it
+            # (seen once as a half-zero result in tests/test_sharded_gpu.py::test_search_on_bare_enqueues_equal_search).
+            import torch
+            torch.cuda.current_stream(lane["packed"].device).synchronize()
             ws = workspace if workspace is not None else self.backend.index.workspace
             st = self._lanes[key] = dict(
                 lane=lane, sp=c_void_p(stream.cuda_stream), ws=ws.data_ptr(),
@@ -138,8 +150,12 @@ class ShardedSearcher:
                 packed=lane["packed"].data_ptr(), flat=lane["flat"].data_ptr(), words=lane["words"],
                 out_s=lane["scores"].data_ptr(), out_i=lane["ids"].data_ptr(), out_f=lane["flags"].data_ptr())
         ix = self.backend.index
-        ix.enqueue_search(q16.data_ptr(), B, k, self.row_base, st["scores_local"], st["ids"], st["exact"],
-                          st["lflags"], st["ws"], st["sp"])
+        ix.enqueue_search(q16.data_ptr(), B, k, 0 if self.id_map is not None else self.row_base, st["scores_local"],
+                          st["ids"], st["exact"], st["lflags"], st["ws"], st["sp"])
+        if self.id_map is not None:   # shards not contiguous in the global numbering: local rows -> global ids (HIP)
+            rc = self.backend.lib.rf_map_ids(st["ids"], B * k, self.id_map.data_ptr(), self.id_map.numel(), st["sp"])
+            if rc:
+                _lib.check(rc)
         if self.world == 1 and not self.force_collective:
             src = st["packed"]
         else:
@@ -186,9 +202,17 @@ class ShardedSearcher:
         return self.backend.merge_packed(flat, lane)
 
     def _map_ids_(self, ids):
-        """local row numbers -> global ids through id_map, in place (-1 stays -1)."""
+        """local row numbers -> global ids through id_map, in place (-1 stays -1).  On the GPU this is
+        one rf_map_ids enqueue on the current stream (no torch math on the N > 1 product path); the
+        torch form below serves the CPU test doubles."""
         import torch
         if self.id_map.numel() == 0:
+            return ids
+        if ids.is_cuda and hasattr(self.backend, "lib") and ids.is_contiguous():
+            with torch.cuda.device(ids.device):
+                _lib.check(self.backend.lib.rf_map_ids(c_void_p(ids.data_ptr()), ids.numel(),
+                                                       c_void_p(self.id_map.data_ptr()), self.id_map.numel(),
+                                                       _lib.current_stream_ptr()))
             return ids
         g = self.id_map[ids.clamp(min=0)]
         ids.copy_(torch.where(ids >= 0, g, ids))
@@ -249,11 +273,40 @@ class ShardedSearcher:
             self.resolve_flagged(q16, k, scores, gids, gflags)
         return scores, gids, gflags
 
+    def poison_step(self, B: int, k: int, device):
+        """This rank could not produce its local answer (its scan raised): enter the SAME collective
+        the healthy ranks are in with an empty answer flagged SHARD_FAILED, so that nobody hangs and
+        every rank learns of the failure from the merged flags."""
+        import torch
+        if hasattr(self.backend, "local_topk_into"):
+            key = (0, B, k)
+            lane = self._lanes.get(key)
+            if lane is None:
+                lane = self._lanes[key] = self.backend.new_lane(B, k, self.world)
+            lane["exact"].fill_(float("-inf"))
+            lane["local_ids"].fill_(-1)
+            lane["local_flags"].fill_(SHARD_FAILED)
+            flat = lane["flat"]
+            self._all_gather(lane["packed"], flat.view(-1))
+            return self.backend.merge_packed(flat, lane)
+        exact = torch.full((B, k), float("-inf"), dtype=torch.float64, device=device)
+        ids = torch.full((B, k), -1, dtype=torch.int64, device=device)
+        flags = torch.full((B,), SHARD_FAILED, dtype=torch.int32, device=device)
+        return self._gather_merge(exact, ids, flags, k)
+
+    @staticmethod
+    def failed(gflags) -> bool:
+        """True when some rank answered with SHARD_FAILED (host sync)."""
+        return bool((gflags < 0).any().item())
+
     def resolve_flagged(self, q16, k: int, scores, gids, gflags) -> int:
         """Re-run the globally flagged queries exhaustively on every shard, merge, patch
         `scores` / `gids` in place.  Collective-safe: gflags is identical on all ranks, so either
-        every rank enters the second all-gather or none does.  Returns the number re-run."""
+        every rank enters the second all-gather or none does.  Returns the number re-run, or -1
+        when a rank reported SHARD_FAILED (then nobody resolves anything: the answer is void)."""
         import torch
+        if self.failed(gflags):                         # host sync; identical on every rank
+            return -1
         bad = torch.nonzero(gflags != 0).flatten()      # host sync
         nb = int(bad.numel())
         if nb == 0:

@@ -25,9 +25,15 @@ from __future__ import annotations
 
 import numpy as np
 
+import logging
+import threading
+
 from . import _lib
 from .sharded import HipShardBackend, ShardedSearcher
 from .store import SCALAR_FIELDS, CorpusStore
+
+
+logger = logging.getLogger(__name__)
 
 
 def _torch():
@@ -54,6 +60,12 @@ class ShardedCorpusStore(CorpusStore):
         self._id_map = torch.empty(0, dtype=torch.int64, device=self.index.device)   # local row -> global id
         self._searcher = None
         self._leading = False
+        # One collective at a time per process: the header / query broadcasts and the all-gather of a search share
+        # the group (and the searcher's lane buffers and the index's default workspace), so two threads of the
+        # serving rank (FastMCP runs the tools on a pool: vector_rag_mcp/main.py:126,135-146) must not interleave
+        # them -- the workers would pair one call's header with another call's queries.  Re-entrant: query() with
+        # vectors and save() take it too.
+        self._coll_lock = threading.RLock()
         on_gpu = dist.get_backend(group) == "nccl"
         self._bdev = self.index.device if on_gpu else torch.device("cpu")
 
@@ -126,17 +138,29 @@ class ShardedCorpusStore(CorpusStore):
         return self._searcher
 
     def _collective_search(self, q16, limit: int):
+        """-> (scores, global ids, merged flags).  A rank whose local part raises still enters the
+        collective (ShardedSearcher.poison_step), so the others do not hang; every rank then sees
+        SHARD_FAILED in the merged flags."""
         torch = _torch()
+        s = self._get_searcher()
+        B = q16.shape[0]
         if limit > _lib.RF_MAX_K:
             # large limits (graph_cons.py:275-281 asks for 1000): each shard's own top-`limit`
             # (paged, exhaustive beyond RF_MAX_K), one all-gather, merge
-            s = self._get_searcher()
-            exact, ids = self._local_large(q16, limit)
-            zero = torch.zeros(q16.shape[0], dtype=torch.int32, device=exact.device)
-            scores, gids, _ = s._gather_merge(exact, ids, zero, limit)
-            return scores, gids
-        scores, gids, _ = self._get_searcher().search(q16, limit)   # flagged queries resolved inside
-        return scores, gids
+            try:
+                exact, ids = self._local_large(q16, limit)
+                flags = torch.zeros(B, dtype=torch.int32, device=exact.device)
+            except Exception:
+                logger.exception("rank %d: local search failed", self.rank)
+                return s.poison_step(B, limit, q16.device)
+            return s._gather_merge(exact, ids, flags, limit)
+        try:
+            scores, gids, gflags = s.search(q16, limit, resolve=False)
+        except Exception:
+            logger.exception("rank %d: local search failed", self.rank)
+            return s.poison_step(B, limit, q16.device)
+        s.resolve_flagged(q16, limit, scores, gids, gflags)   # flagged queries; a no-op for every rank on SHARD_FAILED
+        return scores, gids, gflags
 
     def _local_large(self, q16, limit: int):
         torch = _torch()
@@ -153,14 +177,17 @@ class ShardedCorpusStore(CorpusStore):
         if limit < 1:
             raise ValueError("limit must be >= 1")
         q16 = self._prepare_queries(data).contiguous()
-        if self._leading:
-            hdr = torch.tensor([q16.shape[0], limit], dtype=torch.int64, device=self._bdev)
-            self.dist.broadcast(hdr, src=0, group=self.group)
-            qb = q16.to(self._bdev)
-            self.dist.broadcast(qb, src=0, group=self.group)
-        scores, gids = self._collective_search(q16, limit)
-        kk = min(limit, self.num_entities)
-        return scores[:, :kk].cpu().numpy(), gids[:, :kk].cpu().numpy()
+        with self._coll_lock:   # broadcasts + collective + download as ONE unit (see __init__)
+            if self._leading:
+                hdr = torch.tensor([q16.shape[0], limit], dtype=torch.int64, device=self._bdev)
+                self.dist.broadcast(hdr, src=0, group=self.group)
+                qb = q16.to(self._bdev)
+                self.dist.broadcast(qb, src=0, group=self.group)
+            scores, gids, gflags = self._collective_search(q16, limit)
+            if ShardedSearcher.failed(gflags):
+                raise RuntimeError("sharded search failed: a rank could not scan its shard (see that rank's log)")
+            kk = min(limit, self.num_entities)
+            return scores[:, :kk].cpu().numpy(), gids[:, :kk].cpu().numpy()
 
     # -- serving: ranks > 0 follow rank 0 ---------------------------------------------------------------
     def start_workers(self) -> None:
@@ -178,7 +205,11 @@ class ShardedCorpusStore(CorpusStore):
                 return
             q = torch.empty((B, self.dim), dtype=torch.float16, device=self._bdev)
             self.dist.broadcast(q, src=0, group=self.group)
-            self._collective_search(q.to(self.index.device), k)
+            try:   # a failing scan is reported through the collective itself (SHARD_FAILED); the worker lives on
+                self._collective_search(q.to(self.index.device), k)
+            except Exception:
+                logger.exception("rank %d: search step failed outside the local scan", self.rank)
+                raise
 
     def stop_workers(self) -> None:
         """Rank 0 only: release the ranks parked in start_workers()."""
@@ -194,6 +225,10 @@ class ShardedCorpusStore(CorpusStore):
         if "embedding" not in fields:
             return super().query(expr, limit, fields)
         # COLLECTIVE when vectors are asked for: every rank contributes the rows it owns
+        with self._coll_lock:
+            return self._query_with_vectors(expr, limit, fields)
+
+    def _query_with_vectors(self, expr, limit, fields):
         torch = _torch()
         recs = super().query(expr, limit, [f for f in fields if f != "embedding"] + ["id"])
         want = [self._pk_row[r["id"]] for r in recs]
@@ -219,6 +254,10 @@ class ShardedCorpusStore(CorpusStore):
     # -- persistence: the single-GPU format, written / read in place by every rank (one node) -------------
     def save(self, path: str, chunk_rows: int = 1 << 18) -> None:
         """COLLECTIVE."""
+        with self._coll_lock:
+            self._save(path, chunk_rows)
+
+    def _save(self, path: str, chunk_rows: int) -> None:
         import json
         import os
         n = self.num_entities

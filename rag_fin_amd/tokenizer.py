@@ -245,13 +245,18 @@ class WordPieceTokenizer:
 
     def batch_native(self, texts: list[str], max_length: int = 256, n_threads: int = 0):
         """Same result as batch(), through rf_tokenize_batch.  -> (ids int32 [B, T], lens int32 [B])."""
+        import os
         import numpy as np
+        if n_threads <= 0:
+            n_threads = int(os.environ.get("RAGFIN_TOKENIZER_THREADS", "0") or 0)
         from ctypes import c_void_p
         from . import _lib
+        import time
         lib, h = self._native()
         n = len(texts)
         if n == 0:
             return np.full((0, 1), self.pad_id, dtype=np.int32), np.zeros((0,), dtype=np.int32)
+        t_start = time.perf_counter()
         enc, python_rows = [], {}
         for i, t in enumerate(texts):
             if not t.isascii() and self._complex_re.search(t) is not None:
@@ -269,8 +274,12 @@ class WordPieceTokenizer:
         blob = b"".join(enc)
         ids = np.empty((n, max_length), dtype=np.int32)
         lens = np.empty((n,), dtype=np.int32)
+        t_native = time.perf_counter()
         _lib.check(lib.rf_tokenize_batch(h, blob, c_void_p(offsets.ctypes.data), n, max_length,
                                          c_void_p(ids.ctypes.data), c_void_p(lens.ctypes.data), n_threads))
+        t_done = time.perf_counter()
+        # host seconds of the last call: Python pre-pass (ASCII test, UTF-8 bytes, join) / the native call
+        self.last_timing = {"prepass_s": t_native - t_start, "native_s": t_done - t_native}
         for i, row in python_rows.items():
             ids[i, :] = self.pad_id
             ids[i, :len(row)] = row

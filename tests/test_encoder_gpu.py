@@ -22,6 +22,7 @@ TOL = 4.5e-4          # max-abs per component, fp32 output (3 x 1.5e-4 measured)
 TOL16 = 5e-4          # fp16 output (3 x 1.6e-4)
 TOL_L2 = 2.8e-3       # per-row L2 error (3 x 9.3e-4)
 TOL_COS = 1.3e-6      # 1 - cos (3 x 4.1e-7)
+TRAINED_TOL = 1.9e-3  # trained-like value ranges (test_trained_like_weights...): 3 x the 6.3e-4 measured (profiles/r03_test_measurements.jsonl)
 GOLDEN_TOL = 9e-4     # vs fp32-weight transformers outputs (includes the fp16 rounding of the weights):
                       # 3 x the 3.0e-4 measured on the 6-layer golden (profiles/r02b_test_measurements.jsonl)
 
@@ -66,7 +67,10 @@ def test_encoder_matches_golden_and_oracle(gpu_device, name):
 
 
 @pytest.mark.parametrize("B,T,lo", [(1, 7, 7), (1, 1, 1), (1, 20, 20), (1, 32, 32), (1, 33, 33), (5, 24, 1), (3, 256, 1), (70, 33, 1),
-                                    (16, 128, 100)])   # B = 1, T <= 32: the fused QKV + attention launch of a single query; (5, 24): the one-key-block attention
+                                    (16, 128, 100),
+                                    # T in (256, 512] (the model truncates at 256, vector_rag_mcp/main.py:41, but rf_encode
+                                    # accepts up to max_position): the vector-ALU attention, in each GEMM path
+                                    (2, 300, 1), (3, 512, 200), (20, 512, 300)])   # B = 1, T <= 32: the fused QKV + attention launch of a single query; (5, 24): the one-key-block attention
 def test_encoder_ragged_batches(gpu_device, B, T, lo):
     cfg = dict(oenc.MINILM_L6, layers=2, vocab_size=2000)
     rng = np.random.default_rng(B * 1000 + T)
@@ -257,3 +261,39 @@ def test_large_batch_forward_repeats_bitwise(gpu_device):
         b = emb.encode_ids(ids, lens)
         assert torch.equal(a, b), rnd
         assert bool(torch.isfinite(a.float()).all())
+
+
+def test_trained_like_weights_keep_the_score_bound(gpu_device):
+    """Every other encoder test draws N(0, 0.05^2) weights.  Here: LayerNorm gains U[0.2, 4] with outlier
+    channels at 30, attention logits of several tens, 6 layers, T = 256 (oracle.encoder.trained_like_weights)
+    -- the ranges a trained checkpoint puts on the fp16 activations, the exp2 softmax and the GELU.  A batch
+    of 40 x 256 slots (the large-batch path: k_post_block + MFMA attention) and its probes again one by one
+    (the query path) against the float64 oracle on the same fp16-rounded weights.  Tolerances = 3 x measured
+    (profiles/r03_test_measurements.jsonl); north_star's bound on the SCORE (1e-3) is asserted directly."""
+    from conftest import record_measurement
+    from rag_fin_amd.embedder import Embedder
+    cfg = dict(oenc.MINILM_L6, vocab_size=4000)
+    w = oenc.trained_like_weights(cfg, 23)
+    emb = Embedder(w, cfg, device=gpu_device)
+    rng = np.random.default_rng(9)
+    B, T = 40, 256
+    lens = rng.integers(20, T + 1, B).astype(np.int32)
+    lens[0], lens[1], lens[2] = T, 1, 33
+    ids = rng.integers(1, 4000, (B, T)).astype(np.int32)
+    probes = [0, 1, 2, 5, 11, 17, 23, 39]
+    got = emb.encode_ids(ids, lens, out_dtype="float32").cpu().numpy()
+    assert np.isfinite(got).all()
+    w16 = oenc.round_weights_fp16(w)
+    want = oenc.encode(w16, cfg, ids[probes], lens[probes])
+    hidden = oenc.encode(w16, cfg, ids[probes[:1]], lens[probes[:1]], return_hidden=True)
+    assert np.abs(hidden).max() > 20         # the residual stream really carries outlier channels
+    one = np.stack([emb.encode_ids(ids[p:p + 1, :max(int(lens[p]), 1)], lens[p:p + 1], out_dtype="float32").cpu().numpy()[0]
+                    for p in probes])
+    err_big = np.abs(got[probes] - want).max()
+    err_one = np.abs(one - want).max()
+    cos_gpu, cos_ref = got[probes] @ got[probes].T, want @ want.T
+    score = np.abs(cos_gpu - cos_ref).max()
+    record_measurement("encoder_trained_like_weights", max_abs_large_batch=err_big, max_abs_one_by_one=err_one,
+                       score_diff=score, hidden_max=float(np.abs(hidden).max()))
+    assert score < 1e-3, score                # north_star: scores within 1e-3
+    assert err_big < TRAINED_TOL and err_one < TRAINED_TOL, (err_big, err_one)

@@ -220,3 +220,149 @@ def test_sharded_corpus_store_equals_single_store(tmp_path, world):
     # the saved corpus is the single-GPU format: vectors in GLOBAL row order
     mm = np.fromfile(tmp_path / "corpus" / "vectors.f16", dtype=np.float16).reshape(257, d)
     assert np.array_equal(mm.view(np.uint16), c16.view(np.uint16))
+
+
+# ---- serving: several threads on the leading rank, and a shard that fails -------------------------------
+class FlakyBackend(OracleBackend):
+    """Raises inside the local scan for the searches listed in `fail_calls` (0-based call numbers)."""
+
+    def __init__(self, index, fail_calls=()):
+        super().__init__(index)
+        self.fail_calls, self.calls = set(fail_calls), 0
+
+    def local_topk(self, q16, k, row_base, workspace=None):
+        n = self.calls
+        self.calls += 1
+        if n in self.fail_calls:
+            raise RuntimeError("injected scan failure")
+        return super().local_topk(q16, k, row_base, workspace)
+
+
+def _serving_worker(rank, world, port, out_dir, fail_calls):
+    import threading
+    from rag_fin_amd.sharded_store import ShardedCorpusStore
+    _init(rank, world, port)
+    try:
+        d = 32
+        vec = osearch.synth_unit_rows(301, d, 5).astype(np.float32)
+        st = ShardedCorpusStore("t", dim=d, capacity=8, index=OracleIndex(d, 8), backend=None)
+        st._backend_factory = lambda index: FlakyBackend(index, fail_calls if rank == 1 else ())
+        n = vec.shape[0]
+        st.insert([[f"k{i}" for i in range(n)], ["t"] * n, vec, ["p"] * n, ["c"] * n, ["s"] * n, [0.0] * n])
+        st.flush()
+        st.start_workers()            # ranks > 0 stay inside until released
+        if rank != 0:
+            return
+        q = osearch.synth_unit_rows(24, d, 6).astype(np.float32)
+        out, errors = {}, []
+
+        def client(t):
+            for j in range(6):
+                i = t * 6 + j
+                try:
+                    out[i] = st.search_rows(q[i:i + 1], 5 + (i % 3))[1][0]     # different k per call: a mispaired header shows
+                except RuntimeError as e:
+                    errors.append((i, str(e)))
+        threads = [threading.Thread(target=client, args=(t,)) for t in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=120)
+        alive = any(th.is_alive() for th in threads)
+        after = st.search_rows(q[:1], 5)[1][0] if not alive else None   # the store still works after a failed search
+        st.stop_workers()
+        np.savez(os.path.join(out_dir, "serving.npz"), alive=alive, n_err=len(errors),
+                 err_msgs=np.array([m for _, m in errors] or [""]), err_idx=np.array([i for i, _ in errors] or [-1]),
+                 after=after if after is not None else np.zeros(0), **{f"r{i}": v for i, v in out.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def _serving_expected():
+    d = 32
+    c16 = osearch.l2_normalize_f32(osearch.synth_unit_rows(301, d, 5).astype(np.float32)).astype(np.float16)
+    q16 = osearch.l2_normalize_f32(osearch.synth_unit_rows(24, d, 6).astype(np.float32)).astype(np.float16)
+    return c16, q16
+
+
+def test_threads_on_the_leading_rank_do_not_interleave_collectives(tmp_path):
+    """FastMCP calls the tools from a thread pool (vector_rag_mcp/main.py:126,135-146): four threads x six
+    searches on rank 0 with rank 1 parked in start_workers().  Header broadcast, query broadcast and the
+    all-gather of one call must stay together (ShardedCorpusStore._coll_lock) -- every answer equals the
+    single-store one and nothing hangs."""
+    mp.spawn(_serving_worker, args=(2, _free_port(), str(tmp_path), ()), nprocs=2, join=True)
+    z = np.load(tmp_path / "serving.npz")
+    assert not bool(z["alive"]) and int(z["n_err"]) == 0
+    c16, q16 = _serving_expected()
+    for i in range(24):
+        k = 5 + (i % 3)
+        _, wi = osearch.search(q16[i:i + 1], c16, k)
+        assert np.array_equal(z[f"r{i}"], wi[0]), i
+
+
+def test_a_failing_shard_is_reported_to_the_caller_and_nobody_hangs(tmp_path):
+    """Rank 1's scan raises on its 3rd and 10th search: it still enters the collective (with SHARD_FAILED in
+    its flags), rank 0's search_rows raises for exactly those two calls, every other call is exact, the
+    worker stays alive and the store answers afterwards."""
+    mp.spawn(_serving_worker, args=(2, _free_port(), str(tmp_path), (2, 9)), nprocs=2, join=True)
+    z = np.load(tmp_path / "serving.npz")
+    assert not bool(z["alive"])
+    assert int(z["n_err"]) == 2 and all("a rank could not scan its shard" in m for m in z["err_msgs"])
+    c16, q16 = _serving_expected()
+    failed = set(int(i) for i in z["err_idx"])
+    for i in range(24):
+        if i in failed:
+            continue
+        _, wi = osearch.search(q16[i:i + 1], c16, 5 + (i % 3))
+        assert np.array_equal(z[f"r{i}"], wi[0]), i
+    _, w0 = osearch.search(q16[:1], c16, 5)
+    assert np.array_equal(z["after"], w0[0])
+
+
+# ---- bench.py --gpus N: the answer-check bookkeeping of the strong and the weak job ------------------------
+def _bench_worker(rank, world, port, out_dir):
+    import bench
+    _init(rank, world, port)
+    try:
+        n, d, b, k, nq = 1203, 48, 8, 10, 4
+        # strong job: rank r holds rows shard_bounds(n) of ONE corpus; weak job: every rank its own corpus
+        for label, rows, base, seed in (("strong", None, None, 1234), ("weak", 400, rank * 400, 1234 + rank)):
+            if rows is None:
+                lo, hi = ShardedSearcher.shard_bounds(n, world, rank)
+                c = osearch.synth_unit_rows(n, d, seed)[lo:hi]
+                base = lo
+            else:
+                c = osearch.synth_unit_rows(rows, d, seed)
+            q = osearch.synth_unit_rows(b, d, 5678)
+            ix = OracleIndex(d, max(c.shape[0], 1))
+            ix.add(torch.from_numpy(c))
+            res = ShardedSearcher(OracleBackend(ix), row_base=base).search(torch.from_numpy(q), k, resolve=False)
+            os_l, oi_l = osearch.search(q[:nq], c, k)
+            exp_s, exp_i = bench.gather_expected(os_l, oi_l + base, world, k, torch.device("cpu"))
+            fields = bench.compare_global(res[0].numpy(), res[1].numpy(), exp_s, exp_i, k)
+            clean = bench.all_ranks_agree(int(res[2].abs().sum()) == 0, world, torch.device("cpu"))
+            bad = bench.all_ranks_agree(rank != 1, world, torch.device("cpu"))     # one dissenting rank -> False everywhere
+            np.savez(os.path.join(out_dir, f"b_{label}_{rank}.npz"), exact=fields["global_ids_ranks_exact"],
+                     recall=fields["global_recall_at_10"], err=fields["global_max_abs_score_err"],
+                     nq=fields["global_checked_queries"], clean=clean, bad=bad, exp_i=exp_i)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_global_check_bookkeeping_under_gloo(tmp_path):
+    """bench.py's N > 1 answer check (gather_expected / compare_global / all_ranks_agree: what the strong-scaled
+    headline and the weak job run after their timed regions) at world 2 under gloo with the oracle backend, so
+    that the first real multi-GPU run cannot die in bookkeeping."""
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    n, d, b, k, nq = 1203, 48, 8, 10, 4
+    q = osearch.synth_unit_rows(b, d, 5678)
+    _, wi_strong = osearch.search(q[:nq], osearch.synth_unit_rows(n, d, 1234), k)
+    weak_corpus = np.concatenate([osearch.synth_unit_rows(400, d, 1234 + r) for r in range(world)])
+    _, wi_weak = osearch.search(q[:nq], weak_corpus, k)
+    for label, want in (("strong", wi_strong), ("weak", wi_weak)):
+        for r in range(world):
+            z = np.load(tmp_path / f"b_{label}_{r}.npz")
+            assert bool(z["exact"]) and float(z["recall"]) == 1.0 and float(z["err"]) == 0.0 and int(z["nq"]) == nq
+            assert bool(z["clean"]) and not bool(z["bad"])
+            assert np.array_equal(z["exp_i"], want), (label, r)

@@ -234,3 +234,38 @@ def test_world2_sharded_store_behind_vector_rag(tmp_path, gpu_device):
     for b, ctx in enumerate(got["batch"]):
         assert [int(c["primary_value"]) for c in ctx] == list(oi3[b])
         assert np.allclose([c["score"] for c in ctx], os3[b], atol=1e-6)
+
+
+def test_id_table_is_applied_on_the_device_in_every_step_form(gpu_device):
+    """A shard whose rows are NOT contiguous in the global numbering (ShardedCorpusStore's layout: every
+    insert leaves a slice on every rank): rf_search runs with id_base 0 and rf_map_ids turns local row
+    numbers into global ids on the stream -- in the lane path (`search`), in the bare-enqueue step
+    (`search_on`, which used to ignore the table) and in the raw C call, -1 ("no hit") untouched."""
+    import torch
+    from ctypes import c_void_p
+    from rag_fin_amd import _lib
+    from rag_fin_amd.sharded import HipShardBackend, ShardedSearcher
+    from rag_fin_amd.store import GpuIndex
+    n, d, b, k = 5000, 384, 64, 10
+    c = osearch.synth_unit_rows(n, d, 41)
+    q16 = osearch.synth_unit_rows(b, d, 42)
+    gid = np.random.default_rng(0).permutation(10 * n)[:n].astype(np.int64)      # arbitrary, unique global ids
+    ix = GpuIndex(d, n, gpu_device)
+    ix.add(torch.from_numpy(c).to(gpu_device))
+    q = torch.from_numpy(q16).to(gpu_device)
+    table = torch.from_numpy(gid).to(gpu_device)
+    searcher = ShardedSearcher(HipShardBackend(ix), row_base=0, id_map=table)
+    os_, oi = c_oracle.search(q16, c, k)
+    want = gid[oi]
+    s1, g1, f1 = searcher.search(q, k)
+    assert np.array_equal(g1.cpu().numpy(), want) and int(f1.abs().sum()) == 0
+    st = torch.cuda.Stream(device=gpu_device)
+    s2, g2, f2 = searcher.search_on(q, k, ix.new_workspace(), st)
+    st.synchronize()
+    assert np.array_equal(g2.cpu().numpy(), want) and np.array_equal(s2.cpu().numpy(), os_.astype(np.float32))
+    # the raw call: -1 stays, a row number past the table becomes -1
+    ids = torch.tensor([0, 4999, -1, 5000, 17], dtype=torch.int64, device=gpu_device)
+    with torch.cuda.device(gpu_device):
+        _lib.check(ix.lib.rf_map_ids(c_void_p(ids.data_ptr()), ids.numel(), c_void_p(table.data_ptr()), n,
+                                     _lib.current_stream_ptr()))
+    assert ids.cpu().tolist() == [int(gid[0]), int(gid[4999]), -1, -1, int(gid[17])]

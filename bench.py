@@ -82,11 +82,29 @@ def pmc_traffic(rows, dim, batch):
     return None, None
 
 
-def host_cores():
+def limit_host_pools():
+    """Size the BLAS / OpenMP / torch intra-op pools by the CPUs this process may BURN (a container's CFS quota
+    can sit far below its affinity mask: rag_fin_amd/hostcpu.py), so that the CPU legs are not throttled and
+    `cores` says what really ran.  Returns (budget, the threadpoolctl limiter to keep alive)."""
+    from rag_fin_amd.hostcpu import cpu_budget
+    budget = cpu_budget()
+    keep = None
     try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count()
+        from threadpoolctl import threadpool_limits
+        keep = threadpool_limits(limits=budget)
+    except Exception:
+        pass
+    try:
+        import torch
+        torch.set_num_threads(budget)
+    except Exception:
+        pass
+    return budget, keep
+
+
+def host_cores():
+    from rag_fin_amd.hostcpu import cpu_budget
+    avail = cpu_budget()
     cores = avail
     try:   # the threads the BLAS pool actually runs (it may be capped below the core count)
         from threadpoolctl import threadpool_info
@@ -210,6 +228,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cpu_budget_n, _pool_limit = limit_host_pools()
     # RAGFIN_FORCE_SHARDED=1 at N=1: run the N>1 code path (scan -> RCCL all-gather -> merge) with
     # a one-rank communicator, to measure its per-step overhead on a single-GPU box
     force_sharded = world == 1 and os.environ.get("RAGFIN_FORCE_SHARDED") == "1"
@@ -689,6 +708,7 @@ def config4(args, dev, index1m, lanes, c16_1m, k):
            "encode_s": round(enc_s, 5), "batches": len(batches), "steps": len(t_ids),
            "from_text": {"texts_per_s": round(n / txt_s, 1), "tokens_per_s": round(tokens / txt_s, 1),
                          "text_to_embedding_s": round(txt_s, 5), "host_threads": len(os.sched_getaffinity(0)),
+                         "host_cpu_budget": host_cores(),
                          "what": "native WordPiece tokenizer + chunked pinned uploads + bucketed encode",
                          "host_stage_s": host_stages,
                          "host_stage_note": "host seconds of the last run per stage (the GPU work is only enqueued); "

@@ -340,9 +340,11 @@ class Embedder:
             if pb["done"] is not None:
                 pb["done"].synchronize()      # its previous upload has left the buffers
             tm = lap("pinned_wait_s", tm)
-            pb["ids"][:m * Tc].view(m, Tc).copy_(torch.from_numpy(all_ids))
-            pb["lens"][:m].copy_(torch.from_numpy(all_lens))
-            pb["order"][:m].copy_(torch.from_numpy(order.astype(np.int64)))
+            # numpy views of the pinned buffers: a plain memcpy on this thread (torch's CPU copy_ fans a 4 MB copy
+            # out over every OpenMP thread of the host, which a container's CPU quota punishes: hostcpu.py)
+            pb["ids"].numpy()[:m * Tc].reshape(m, Tc)[...] = all_ids
+            pb["lens"].numpy()[:m] = all_lens
+            pb["order"].numpy()[:m] = order
             tm = lap("pinned_stage_s", tm)
             with torch.cuda.stream(self._copy_stream):
                 ids_dev = pb["ids"][:m * Tc].view(m, Tc).to(self.device, non_blocking=True)

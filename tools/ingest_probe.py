@@ -19,7 +19,10 @@ emb = Embedder(oenc.random_weights(cfg, 0), cfg, tokenizer=tok, device=dev)
 texts = synth_text.retemplated_texts(10000, 11)
 emb.encode_to_device(texts[:256]); torch.cuda.synchronize()
 print("affinity", len(os.sched_getaffinity(0)))
-for nt in (0, 8, 16, 32):
+import torch as _t
+from rag_fin_amd.hostcpu import cpu_budget
+print("cpu budget", cpu_budget(), "torch threads", _t.get_num_threads())
+for nt in (0, 8, 16, 64):
     os.environ["RAGFIN_TOKENIZER_THREADS"] = str(nt)
     tot = []
     for r in range(5):

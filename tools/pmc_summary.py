@@ -35,7 +35,7 @@ def main():
                 vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     per = {}
     for kname, counters in vals.items():
-        if not any(t in kname for t in ("k_scan", "k_merge", "k_threshold", "k_linear", "k_gemm", "k_attention", "k_embed", "k_pool")):
+        if not any(t in kname for t in ("k_scan", "k_merge", "k_threshold", "k_linear", "k_gemm", "k_attention", "k_embed", "k_pool", "k_post")):
             continue
         rec = {}
         for cname, xs in counters.items():

@@ -149,15 +149,6 @@ void rf_launch_post_pack_build(const rf_encoder_weights* w, void* pack, int L, h
   hipLaunchKernelGGL(k_post_pack_build, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ps, (uint4*)pack, L);
 }
 
-// ---- compile-time loops ---------------------------------------------------------------------------
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
-
 // ---- GELU of one FFN1 block (16 values per lane), cut into 136 slots -------------------------------
 // gelu(y) = y Phi(y) = max(y, 0) - |y| Phi(-|y|), and log2 Phi(-t) is so smooth that a degree-5 polynomial in
 // t = |y| (weighted minimax fit on [0, 6], tools/fit_gelu.py) gives |error| <= 6.4e-7 over |y| <= 40 -- thirty
@@ -185,7 +176,7 @@ __device__ __forceinline__ void gelu_slot(const f32x16& y, GeluTmp& g, uint32_t 
   } else if constexpr (w < 28) {
     constexpr int v = (w - 20) >> 1;
     if constexpr (((w - 20) & 1) == 0) g.p[v] = __builtin_amdgcn_exp2f(g.p[v]);
-    else g.r[v] = __builtin_fmaxf(y[4 * quad + v], 0.f);
+    else g.r[v] = __builtin_amdgcn_fmed3f(y[4 * quad + v], 0.f, __builtin_inff());   // max(y, 0) in ONE operation (fmaxf costs a canonicalising v_max first)
   } else if constexpr (w < 32) {
     constexpr int v = w - 28;
     g.p[v] = __builtin_fmaf(-__builtin_fabsf(y[4 * quad + v]), g.p[v], g.r[v]);
@@ -207,41 +198,8 @@ __device__ __forceinline__ void gload16(rf_u32x4& d, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
 }
 
-// ---- LDS fragment reads of a ring step: pairs of fragments, four register pairs, three pairs ahead ----
-// One ds_read_b128 per MFMA, all four waves of the CU: the LDS runs at half its rate and a read issued four
-// MFMAs (128 cycles) ahead is late (stamps: 60 cycles per MFMA in the out-projection steps with groups of four
-// read one group ahead).  Pair g (MFMAs 2 g, 2 g + 1) is read while pair g - 3 computes: six MFMAs of lead,
-// the same 32 registers.  run_step<NM>(frag_of, sa, body): frag_of(n) = fragment of MFMA n (a constexpr
-// callable), body(n_c, fragment registers) issues MFMA n and whatever rides in its gap.
-template <int N>
-__device__ __forceinline__ void lds_wait_pair(rf_u32x4 (&d)[2]) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(d[0]), "+v"(d[1]) : "n"(N));
-}
-template <int NM, class FragOf, class Body>
-__device__ __forceinline__ void run_step(FragOf frag_of, uint32_t sa, Body&& body) {
-  constexpr int NP = NM / 2;   // pairs
-  rf_u32x4 fa[4][2];
-  auto read_pair = [&](auto Gc) __attribute__((always_inline)) {
-    constexpr int G = decltype(Gc)::value;
-    lds_read_frag<frag_of(2 * G)>(fa[G & 3][0], sa);
-    lds_read_frag<frag_of(2 * G + 1)>(fa[G & 3][1], sa);
-  };
-  static_for<0, (NP < 3 ? NP : 3)>([&](auto Gc) __attribute__((always_inline)) { read_pair(Gc); });
-  static_for<0, NP>([&](auto Gc) __attribute__((always_inline)) {
-    constexpr int G = decltype(Gc)::value;
-    // pair G + 3 is read BEHIND the pair's first MFMA (its two issue slots sit in that MFMA's shadow, not in front
-    // of it together with the previous gap's vector work and LDS-DMA piece): pairs read after pair G at its wait = 2
-    constexpr int newer = (NP - 1 - G) < 2 ? (NP - 1 - G) : 2;
-    lds_wait_pair<2 * newer>(fa[G & 3]);
-    body(std::integral_constant<int, 2 * G>{}, fa[G & 3][0]);
-    if constexpr (G + 3 < NP) read_pair(std::integral_constant<int, G + 3>{});
-    body(std::integral_constant<int, 2 * G + 1>{}, fa[G & 3][1]);
-  });
-}
-
-
 // DBG: clock stamps per wave into a.dbg.  ABL (experiments build; results wrong): 1 = no LDS-DMA in the MLP
-// steps, 2 = no GELU, 8 = no MFMAs in the MLP steps, 4 = QKV phase on accumulator-half (builtin) MFMAs.
+// steps, 2 = no GELU, 8 = no MFMAs in the MLP steps, 4 = QKV phase on accumulator-half (builtin) MFMAs, 16 = QKV stores into an L2-resident window.
 template <int DBG, int ABL>
 __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_block(const rf_post_args a) {
   constexpr int KS = HID / 16;   // 24
@@ -584,7 +542,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   // tiles, nobody reads rows past the token count): exactly four per step, which the counted waits rely on.
   if (a.qkv_out) {
     f32x16 qa[2][2];   // [step parity][block of the step]
-    _Float16* const qdst = a.qkv_out + (tb * (3 * KS) * 64 + lane) * 8;
+    // (ABL 16: every workgroup stores into the first tile's rows -- an L2-resident window: what the stores cost without HBM)
+    _Float16* const qdst = a.qkv_out + (((ABL & 16) ? (size_t)wave : tb) * (3 * KS) * 64 + lane) * 8;
     uint32_t pkw[8];
     uint32_t sw[4];
     auto epi_slot = [&](auto Oc, const f32x16 (&src)[2], int blk0) __attribute__((always_inline)) {
@@ -704,6 +663,7 @@ int rf_launch_post_block(const rf_post_args& a_in, int token_slots, hipStream_t 
       case 3: RF_PB_LAUNCH(1, 3);
       case 8: RF_PB_LAUNCH(1, 8);
       case 4: RF_PB_LAUNCH(1, 4);
+      case 16: RF_PB_LAUNCH(1, 16);
       default: RF_PB_LAUNCH(1, 0);
     }
   }

@@ -10,6 +10,7 @@
 // consume them cannot be scheduled above it.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 
 #ifndef RF_U32X4_DEFINED
 #define RF_U32X4_DEFINED
@@ -45,3 +46,47 @@ template <int N>
 __device__ __forceinline__ void lds_wait_group(rf_u32x4 (&d)[WL_GRP]) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(N));
 }
+
+// ---- compile-time loops ---------------------------------------------------------------------------
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+
+// ---- LDS fragment reads of a ring step: pairs of fragments, four register pairs, three pairs ahead ----
+// One ds_read_b128 per MFMA, all four waves of the CU: the LDS runs at half its rate and a read issued four
+// MFMAs (128 cycles) ahead is late (stamps: 60 cycles per MFMA in the out-projection steps with groups of four
+// read one group ahead).  Pair g (MFMAs 2 g, 2 g + 1) is read while pair g - 3 computes: six MFMAs of lead,
+// the same 32 registers.  run_step<NM>(frag_of, sa, body): frag_of(n) = fragment of MFMA n (a constexpr
+// callable), body(n_c, fragment registers) issues MFMA n and whatever rides in its gap.
+template <int N>
+__device__ __forceinline__ void lds_wait_pair(rf_u32x4 (&d)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(d[0]), "+v"(d[1]) : "n"(N));
+}
+template <int NM, class FragOf, class Body>
+__device__ __forceinline__ void run_step(FragOf frag_of, uint32_t sa, Body&& body) {
+  constexpr int NP = NM / 2;   // pairs
+  rf_u32x4 fa[4][2];
+  auto read_pair = [&](auto Gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(Gc)::value;
+    lds_read_frag<frag_of(2 * G)>(fa[G & 3][0], sa);
+    lds_read_frag<frag_of(2 * G + 1)>(fa[G & 3][1], sa);
+  };
+  static_for<0, (NP < 3 ? NP : 3)>([&](auto Gc) __attribute__((always_inline)) { read_pair(Gc); });
+  static_for<0, NP>([&](auto Gc) __attribute__((always_inline)) {
+    constexpr int G = decltype(Gc)::value;
+    // pair G + 3 is read BEHIND the pair's first MFMA (its two issue slots sit in that MFMA's shadow, not in front
+    // of it together with the previous gap's vector work and LDS-DMA piece): pairs read after pair G at its wait = 2
+    constexpr int newer = (NP - 1 - G) < 2 ? (NP - 1 - G) : 2;
+    lds_wait_pair<2 * newer>(fa[G & 3]);
+    body(std::integral_constant<int, 2 * G>{}, fa[G & 3][0]);
+    if constexpr (G + 3 < NP) read_pair(std::integral_constant<int, G + 3>{});
+    body(std::integral_constant<int, 2 * G + 1>{}, fa[G & 3][1]);
+  });
+}
+
+

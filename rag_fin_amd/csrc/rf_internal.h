@@ -54,6 +54,7 @@ RF_KNOB(rf_knob_emit_wgs_per_cu, 0)    // emit grid = CUs x this (0 = default fo
 RF_KNOB(rf_knob_sample_bpw, 2)         // sample blocks per wave
 RF_KNOB(rf_knob_wide_sample_pairs, 4)  // wide sample pass: block pairs per workgroup, at most
 RF_KNOB(rf_knob_wide_dbg, 0)           // wide sweep diagnostic bits (clock stamps, cached-KiB ablation)
+RF_KNOB(rf_knob_wide_form, 0)          // wide sweep kernel: 0 = eight waves x 32 queries (k_scan_w16), 1 = four waves x 64 queries (k_scan_w64)
 RF_KNOB(rf_knob_wide_ne, 0)            // wide sweep: LDS-DMA pieces per phase of waves 0-3 (0 = the product's split)
 RF_KNOB(rf_knob_linear_dma, 1)         // encoder: K = 384 plain-epilogue GEMMs through the LDS-DMA ring (0 off, 1 auto, 2 always 256-token, 3 never 256-token)
 RF_KNOB(rf_knob_linear_small, 1)       // encoder: feature-split GEMMs + separate LayerNorm at <= 1024 token slots

@@ -215,7 +215,7 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t st) {
 // experiments build (tools/ only) makes them process-wide ints behind rf_set_tuning -----------
 #ifdef RF_EXPERIMENTS
 int rf_knob_ring24 = 8, rf_knob_emit_wgs_per_cu = 0, rf_knob_sample_bpw = 2;
-int rf_knob_wide_sample_pairs = 4, rf_knob_wide_dbg = 0, rf_knob_wide_ne = 0;
+int rf_knob_wide_sample_pairs = 4, rf_knob_wide_dbg = 0, rf_knob_wide_ne = 0, rf_knob_wide_form = 0;
 int rf_knob_linear_dma = 1, rf_knob_linear_small = 1, rf_knob_k384_ntb = 4, rf_knob_ffn2_ntb = 4;
 int rf_knob_gemm_tile = 3, rf_knob_encode_graph = 1, rf_knob_linear_dbg = 0, rf_knob_debug_epi = 1, rf_knob_att_heads = 1, rf_knob_gemm_tile_dma = 0, rf_knob_one_query = 1, rf_knob_post_block = 1, rf_knob_post_dbg = 0, rf_knob_post_qkv = 1;
 int rf_tuning_generation = 0;
@@ -230,7 +230,7 @@ extern "C" int rf_set_tuning(const char* key, int value) {
   struct K { const char* name; int* var; int lo, hi; };
   const K keys[] = {{"ring24", &rf_knob_ring24, 6, 24}, {"emit_wgs_per_cu", &rf_knob_emit_wgs_per_cu, 0, 4},
                     {"sample_bpw", &rf_knob_sample_bpw, 1, 8}, {"wide_sample_pairs", &rf_knob_wide_sample_pairs, 1, 8},
-                    {"wide_dbg", &rf_knob_wide_dbg, 0, 127}, {"wide_ne", &rf_knob_wide_ne, 0, 112}, {"linear_dma", &rf_knob_linear_dma, 0, 3},
+                    {"wide_dbg", &rf_knob_wide_dbg, 0, 127}, {"wide_ne", &rf_knob_wide_ne, 0, 112}, {"wide_form", &rf_knob_wide_form, 0, 1}, {"linear_dma", &rf_knob_linear_dma, 0, 3},
                     {"linear_small", &rf_knob_linear_small, 0, 1}, {"k384_ntb", &rf_knob_k384_ntb, 2, 4},
                     {"ffn2_ntb", &rf_knob_ffn2_ntb, 2, 4}, {"gemm_tile", &rf_knob_gemm_tile, 0, 15}, {"encode_graph", &rf_knob_encode_graph, 0, 1},
                     {"linear_dbg", &rf_knob_linear_dbg, 0, 63}, {"debug_epi", &rf_knob_debug_epi, 0, 5}, {"post_block", &rf_knob_post_block, 0, 1}, {"post_dbg", &rf_knob_post_dbg, 0, 63}, {"post_qkv", &rf_knob_post_qkv, 0, 1}, {"att_heads", &rf_knob_att_heads, 1, 2}, {"one_query", &rf_knob_one_query, 0, 1}, {"gemm_tile_dma", &rf_knob_gemm_tile_dma, 0, 2}};

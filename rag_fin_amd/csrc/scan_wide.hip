@@ -675,6 +675,288 @@ __global__ void __launch_bounds__(512, 1) k_scan_w16(WideParams p) {
   }
 }
 
+// =========================================================================================
+// The sweep, round 3: FOUR waves of 64 queries, one wave per SIMD
+// =========================================================================================
+// k_scan_w16 above puts two waves on every SIMD (238 registers each).  Its stamps and ablations
+//  say that this two-wave structure itself packs the matrix pipe to ~80 % at best:
+// one barrier per 96 MFMAs for eight waves, every A operand read from LDS feeding two MFMAs, two
+// in-order instruction streams arbitrating for one pipe.  Round 3's encoder kernel (encoder_post.hip)
+// showed what ONE wave per SIMD with the whole register file does on this part when its stream is
+// laid out for in-order issue -- LDS reads a few MFMAs ahead, LDS-DMA pieces from scalar addresses,
+// nothing else in the loop: 83-88 % of the pipe in its MFMA-only phases.  Here:
+//   * a wave keeps 64 queries (four 16-query groups x 12 k-steps = 192 registers, accumulator
+//     half of the file) resident; every A operand read from LDS (16 rows x 32 k, 1 KiB) feeds FOUR
+//     MFMAs: half the LDS traffic and half the read instructions per MFMA of the 8-wave form, and a
+//     quarter of the workgroup barriers' participants;
+//   * the accumulators live in the vector half (inline-asm MFMAs with vector-register C / D), so
+//     the filter's v_max3 read them in place;
+//   * the corpus ring is unchanged (3 slots x 2 blocks, two phases ahead, counted vmcnt + one raw
+//     s_barrier per phase); its pieces are issued from wave-uniform scalar addresses (inline asm:
+//     no address VALU, and the compiler-visible LDS / memory operations of the rare flush draw no
+//     vmcnt(0));
+//   * filter, append and flush are k_scan_w16's (same staging entries).
+// (First form tried: 16x16x32 MFMAs as in k_scan_w16 -- correct, 206 us against 182: a 16-cycle MFMA holds the
+// vector issue for 8 of its 16 cycles, which leaves a single in-order wave no room for its LDS reads, LDS-DMA
+// pieces and filter: 164 us without the filters, 188 without the pieces.  The 32x32x16 form below has 24 free
+// issue cycles per MFMA; its filter is cut into single operations that ride in the MFMA gaps, far enough behind
+// the accumulator's last MFMA to need no hazard nops.)
+#define W64_ENTRY_WORDS 20   // { row of score 0, query, threshold, pad, 16 scores }: a lane's whole 16-row column
+template <class P>
+__device__ __forceinline__ void w64_flush(W16Stage& st, const P& p, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  for (uint32_t i = lane; i < st.cnt * 16u; i += 64) {
+    const uint32_t* e = st.base + (i >> 4) * W64_ENTRY_WORDS;
+    const uint32_t s = i & 15u;
+    const float score = __builtin_bit_cast(float, e[4 + s]);
+    const uint32_t row = e[0] + (s & 3u) + 8u * (s >> 2);   // acc_row(s, h) with 4 h folded into e[0]
+    if (score >= __builtin_bit_cast(float, e[2]) && row < p.n_rows) {
+      const uint32_t list = e[1] * RF_CAND_SHARDS + (blockIdx.x & (RF_CAND_SHARDS - 1));
+      const uint32_t slot = atomicAdd(&p.cand_cnt[list], 1u);
+      if (slot < p.cap) p.cand[(size_t)list * p.cap + slot] = make_uint2(row, __builtin_bit_cast(uint32_t, score));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  st.cnt = 0;
+}
+template <int CAP_E, class P>
+__device__ __forceinline__ void w64_append(const f32x16& a, unsigned long long mask, float th, uint32_t row0, uint32_t q,
+                                           int lane, W16Stage& st, const P& p) {
+  const uint32_t n = (uint32_t)__popcll(mask);
+  const bool ok = (mask >> lane) & 1ull;
+  if (st.cnt + n <= (uint32_t)CAP_E) {
+    if (ok) {
+      // inline-asm stores (nothing here may draw a compiler wait on the corpus ring)
+      const uint32_t e = st.base_addr + (st.cnt + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) * (W64_ENTRY_WORDS * 4);
+      const u32x4 hdr = {row0 + 4u * (uint32_t)(lane >> 5), q, __builtin_bit_cast(uint32_t, th), 0u};
+      const f32x4 s0 = {a[0], a[1], a[2], a[3]}, s1 = {a[4], a[5], a[6], a[7]}, s2 = {a[8], a[9], a[10], a[11]},
+                  s3 = {a[12], a[13], a[14], a[15]};
+      asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32\n\t"
+                   "ds_write_b128 %0, %4 offset:48\n\tds_write_b128 %0, %5 offset:64"
+                   :: "v"(e), "v"(hdr), "v"(s0), "v"(s1), "v"(s2), "v"(s3) : "memory");
+    }
+    st.cnt += n;
+  } else if (ok) {   // staging full within one phase (adversarial duplicates): flag the query
+    atomicAdd(&p.cand_cnt[q * RF_CAND_SHARDS + (blockIdx.x & (RF_CAND_SHARDS - 1))], p.cap + 1u);
+  }
+}
+
+template <int MODE, int DBG>
+__global__ void __launch_bounds__(256, 1) k_scan_w64(WideParams p) {
+  constexpr int NW = 4;
+  constexpr int NP = WL_FRAGS / NW;                               // LDS-DMA pieces per wave and phase (12)
+  constexpr int CAP_E = WL_STAGE_WORDS / NW / W64_ENTRY_WORDS;    // emit staging entries per wave: 38
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* slots = (u32x4*)smem_raw;
+  uint32_t* stage = (uint32_t*)(slots + WL_SLOTS * WL_FRAGS * 64);
+  u32x4* const dump = (u32x4*)(stage + WL_STAGE_WORDS);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const uint32_t G = gridDim.x;
+  const uint32_t cnt = (p.n_work > blockIdx.x) ? (p.n_work - blockIdx.x + G - 1) / G : 0u;
+  if (cnt == 0) return;  // workgroup-uniform
+  const uint32_t nblk = (p.n_rows + 31u) >> 5;
+
+  // A phase is 48 fragments (two blocks, contiguous in HBM); wave w brings fragments 12 w .. 12 w + 11.  Past the
+  // end of the stream the pieces re-read the corpus' last block into the dump area, and so does the second block
+  // of an odd tail (its rows are masked by row1): the same 12 pieces per wave in every phase.
+  const uint32_t slots_s = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)slots;
+  const uint32_t dump_s = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)dump;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  struct Pieces {
+    const char* src;    // fragment 0 of the phase's first block (wave-uniform)
+    uint32_t dst;       // LDS byte address of fragment 0 of the slot, or of the dump area
+    uint32_t dstep;     // 1024 | 0
+    uint32_t cut;       // fragments >= cut come from 24 fragments further back
+  };
+  auto pieces_of = [&](uint32_t ph) __attribute__((always_inline)) {
+    const bool live = ph < cnt;
+    uint32_t b = (blockIdx.x + ph * G) * p.bstride * WL_PB;
+    Pieces pc;
+    pc.cut = (live && b + 1u < nblk) ? 2u * WIDE_KS : (uint32_t)WIDE_KS;
+    b = (live && b < nblk) ? b : nblk - 1u;
+    pc.src = (const char*)p.corpus + (size_t)b * (WIDE_KS * RF_FRAG_BYTES);
+    pc.dst = live ? slots_s + (ph % WL_SLOTS) * (uint32_t)(WL_FRAGS * RF_FRAG_BYTES) : dump_s;
+    pc.dstep = live ? (uint32_t)RF_FRAG_BYTES : 0u;
+    return pc;
+  };
+  auto issue_piece = [&](const Pieces& pc, int j) __attribute__((always_inline)) {
+    const uint32_t f = (uint32_t)(wave * NP + j);
+    const uint32_t fs = (DBG & 1) ? 0u : (f >= pc.cut ? f - (uint32_t)WIDE_KS : f);   // DBG 1: every piece re-reads one cached KiB
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
+                 :: "s"(pc.dst + f * pc.dstep), "v"(lane_off), "s"(pc.src + (size_t)fs * RF_FRAG_BYTES) : "memory");
+  };
+  {
+    const Pieces p0 = pieces_of(0), p1 = pieces_of(1);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue_piece(p0, j);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue_piece(p1, j);
+  }
+
+  // this wave's 64 queries (two blocks of 32) as B operands of the 32x32x16 MFMA, resident for the whole sweep
+  u32x4 qf[2][WIDE_KS];
+  float th[2];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    const int qi = wave * 64 + jb * 32 + c;
+    const int qc = qi < p.B ? qi : p.B - 1;   // unconditional loads (no branch per fragment)
+#pragma unroll
+    for (int kk = 0; kk < WIDE_KS; ++kk)
+      qf[jb][kk] = *(const u32x4*)(p.q + (size_t)qc * (WIDE_KS * 16) + kk * 16 + h * 8);
+    th[jb] = (MODE == MODE_EMIT) ? p.thr[qc] : 0.f;
+    if (qi >= p.B || (DBG & 1)) th[jb] = INFINITY;
+  }
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    const int qi = wave * 64 + jb * 32 + c;
+#pragma unroll
+    for (int kk = 0; kk < WIDE_KS; ++kk) {
+      u32x4 v = qf[jb][kk];
+      if (qi >= p.B) v = u32x4{0u, 0u, 0u, 0u};
+      asm volatile("" : "+a"(v));   // resident in the accumulator half: the vector half stays free for accumulators and operands
+      qf[jb][kk] = v;
+    }
+  }
+  float pm[2] = {-INFINITY, -INFINITY};
+  W16Stage st;
+  st.cnt = 0;
+  st.base = stage + wave * (WL_STAGE_WORDS / NW);
+  st.base_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)st.base;
+
+  // [phase parity][block of the phase][query block]: lane = query c, register i = row acc_row(i, h) of the block.
+  // FOUR accumulation chains rotate (the phase's two blocks advance together, k-step by k-step): a dependent MFMA
+  // with vector-register C / D issued two slots behind its predecessor waits for the write-back (the encoder's QKV
+  // phase, two such chains: 49 cycles per MFMA against 38) -- at distance four it does not.  Both blocks therefore
+  // finish with the phase's last MFMAs, and their filter rides under the NEXT phase's MFMAs: two accumulator sets.
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a_][b][jb][r] = -INFINITY;
+  // The filter of one 32-row block as 18 single operations (per query block: 8 v_max3 over the 16 rows, then the
+  // compare against the query's threshold / the running sample maximum), one per fragment of the stream, so that
+  // each rides in the shadow of an MFMA pair.  The block's accumulators were finished at least four MFMAs earlier.
+  float fm[2];
+  unsigned long long hit[2];
+  auto filter_slot = [&](auto Tc, f32x16 (&a)[2]) __attribute__((always_inline)) {
+    constexpr int T = decltype(Tc)::value, jb = T / 9, w = T % 9;
+    if constexpr (w == 0) fm[jb] = vmax3(a[jb][0], a[jb][1], a[jb][1]);
+    else if constexpr (w < 8) fm[jb] = vmax3(fm[jb], a[jb][2 * w], a[jb][2 * w + 1]);
+    else if constexpr (MODE == MODE_SAMPLE) pm[jb] = vmax3(pm[jb], fm[jb], fm[jb]);
+    else hit[jb] = __builtin_amdgcn_fcmpf(fm[jb], th[jb], 3 /* FCMP_OGE */);
+  };
+  auto mask_tail = [&](f32x16 (&a)[2], uint32_t row0) __attribute__((always_inline)) {
+    if (MODE == MODE_SAMPLE && row0 + 32u > p.n_rows) {   // wave-uniform: the corpus' last block / a block past the end
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (row0 + acc_row(r, h) >= p.n_rows) a[jb][r] = -INFINITY;
+    }
+  };
+  auto take_hits = [&](f32x16 (&a)[2], uint32_t row0) __attribute__((always_inline)) {
+    if (MODE == MODE_EMIT && (hit[0] | hit[1]) != 0ull) {
+      const uint32_t q0 = (uint32_t)(wave * 64 + c);
+      if (hit[0] != 0ull) w64_append<CAP_E>(a[0], hit[0], th[0], row0, q0, lane, st, p);
+      if (hit[1] != 0ull) w64_append<CAP_E>(a[1], hit[1], th[1], row0, q0 + 32u, lane, st, p);
+    }
+  };
+  uint32_t row0_prev = p.n_rows, row1_prev = p.n_rows;
+  uint64_t t_wait = 0, t_c0 = 0, t_r0 = 0;
+  if (DBG & 4) {
+    t_c0 = __builtin_amdgcn_s_memtime();
+    t_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+
+  auto phase = [&](uint32_t ph, auto parc) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(parc)::value;
+    uint64_t ts0 = 0;
+    if (DBG & 4) ts0 = __builtin_amdgcn_s_memtime();
+    // my pieces of phase ph have landed (my 12 pieces of phase ph + 1 may stay in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    // ... and after the barrier everybody's have, and everybody has consumed phase ph - 1
+    __builtin_amdgcn_s_barrier();
+    if (DBG & 4) t_wait += __builtin_amdgcn_s_memtime() - ts0;
+    const Pieces nxt = pieces_of(ph + 2);  // goes into the slot phase ph - 1 has just vacated
+    const uint32_t sa = slots_s + (ph % WL_SLOTS) * (uint32_t)(WL_FRAGS * RF_FRAG_BYTES) + lane_off;
+    const uint32_t b0 = (blockIdx.x + ph * G) * p.bstride * WL_PB;
+    const uint32_t row0 = (b0 < nblk) ? b0 * 32u : p.n_rows;
+    const uint32_t row1 = (b0 + 1u < nblk) ? (b0 + 1u) * 32u : p.n_rows;
+    // the one flush site of the loop (the append path never flushes)
+    if (MODE == MODE_EMIT && st.cnt >= (uint32_t)CAP_E / 4) w64_flush(st, p, lane);
+    // item n of the phase: block n & 1, k-step n >> 1 (fragment 24 (n & 1) + (n >> 1) of the slot); two MFMAs per item
+    run_step<WL_FRAGS>([](int n) constexpr { return (n & 1) * WIDE_KS + (n >> 1); }, sa,
+                       [&](auto Nc, const rf_u32x4& af) __attribute__((always_inline)) {
+      constexpr int n = decltype(Nc)::value, blk = n & 1, kk = n >> 1;
+      if constexpr (kk == 0) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[PAR][blk][0]) : "v"(af), "a"(qf[0][kk]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc[PAR][blk][1]) : "v"(af), "a"(qf[1][kk]));
+      } else {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[PAR][blk][0]) : "v"(af), "a"(qf[0][kk]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[PAR][blk][1]) : "v"(af), "a"(qf[1][kk]));
+      }
+      if constexpr (!(DBG & 2)) {
+        // the previous phase's two blocks (the other accumulator set) are filtered under items 2..19 and 20..37
+        if constexpr (n == 2) mask_tail(acc[PAR ^ 1][0], row0_prev);
+        if constexpr (n >= 2 && n < 20) filter_slot(std::integral_constant<int, n - 2>{}, acc[PAR ^ 1][0]);
+        if constexpr (n == 20) {
+          take_hits(acc[PAR ^ 1][0], row0_prev);
+          mask_tail(acc[PAR ^ 1][1], row1_prev);
+        }
+        if constexpr (n >= 20 && n < 38) filter_slot(std::integral_constant<int, n - 20>{}, acc[PAR ^ 1][1]);
+        if constexpr (n == 38) take_hits(acc[PAR ^ 1][1], row1_prev);
+      }
+      if constexpr ((n & 3) == 3 && !(DBG & 8)) issue_piece(nxt, n >> 2);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    row0_prev = row0;
+    row1_prev = row1;
+  };
+  for (uint32_t ph = 0; ph < cnt; ++ph) {
+    if (ph & 1u) phase(ph, std::integral_constant<int, 1>{});
+    else phase(ph, std::integral_constant<int, 0>{});
+  }
+  if (!(DBG & 2)) {   // the last phase's blocks: their MFMAs have only just been issued -- pad the XDL write hazard by hand
+    auto tail = [&](f32x16 (&a)[2][2]) __attribute__((always_inline)) {
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]));
+      mask_tail(a[0], row0_prev);
+      static_for<0, 18>([&](auto Tc) __attribute__((always_inline)) { filter_slot(Tc, a[0]); });
+      take_hits(a[0], row0_prev);
+      mask_tail(a[1], row1_prev);
+      static_for<0, 18>([&](auto Tc) __attribute__((always_inline)) { filter_slot(Tc, a[1]); });
+      take_hits(a[1], row1_prev);
+    };
+    if ((cnt - 1u) & 1u) tail(acc[1]);
+    else tail(acc[0]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dump pieces must land before the LDS is handed on
+  if ((DBG & 4) && p.pmax && lane == 0) {   // diagnostic run only (tools/bench_wide.py --dbg 4)
+    float* o = p.pmax + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = (float)(__builtin_amdgcn_s_memtime() - t_c0);
+    o[1] = (float)(__builtin_amdgcn_s_memrealtime() - t_r0);
+    o[2] = (float)t_wait;   // cycles in the vmcnt wait + barrier
+    o[3] = (float)cnt;
+    o[4] = 0.f;
+  }
+  if (MODE == MODE_EMIT) {
+    if (st.cnt > 0) w64_flush(st, p, lane);
+  } else {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const int qi = wave * 64 + jb * 32 + c;
+      const float m = fmaxf(pm[jb], __shfl_xor(pm[jb], 32));
+      if (h == 0 && qi < p.B) p.pmax[(size_t)qi * p.P + blockIdx.x] = m;
+    }
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------
 static size_t wide_lds_bytes() {
   return (size_t)WL_SLOTS * WL_FRAGS * RF_FRAG_BYTES + (size_t)WL_STAGE_WORDS * 4 + (size_t)RF_FRAG_BYTES;   // slots, emit staging, dump area
@@ -700,9 +982,24 @@ static int launch_ldsdma(const WideParams& p, int grid, hipStream_t st) {
   return RF_OK;
 }
 #endif
+template <int MODE, int DBG>
+static int launch_w64(const WideParams& p, int grid, hipStream_t st) {
+  auto kern = k_scan_w64<MODE, DBG>;
+  static rf_lds_attr attr;   // per instantiation, per device
+  RF_HIP(rf_ensure_lds(attr, (const void*)kern, wide_lds_bytes()));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), wide_lds_bytes(), st, p);
+  RF_HIP(hipGetLastError());
+  return RF_OK;
+}
 template <int MODE>
 static int dispatch_ldsdma(const WideParams& p, int grid, hipStream_t st) {
 #ifdef RF_EXPERIMENTS
+  if (rf_knob_wide_form == 1) {   // rf_set_tuning("wide_form", 1): four waves x 64 queries (round 3)
+    if ((rf_knob_wide_dbg & 63) == 4) return launch_w64<MODE, 4>(p, grid, st);
+    if ((rf_knob_wide_dbg & 63) == 2 && MODE == MODE_EMIT) return launch_w64<MODE, 2>(p, grid, st);
+    if ((rf_knob_wide_dbg & 63) == 8 && MODE == MODE_EMIT) return launch_w64<MODE, 8>(p, grid, st);
+    return launch_w64<MODE, 0>(p, grid, st);
+  }
   // rf_set_tuning("wide_dbg", bits): 1 = every DMA piece re-reads one cached KiB, 2 = no filters, 4 = clock
   // stamps, 8 = no LDS-DMA in the loop (1 | 2 | 8: results wrong); 64 = the round-1 kernel (32x32x16 MFMA)
   if (rf_knob_wide_dbg & 64) return launch_ldsdma<MODE, 2, 8>(p, grid, st);
@@ -727,6 +1024,8 @@ static int dispatch_ldsdma(const WideParams& p, int grid, hipStream_t st) {
       default: break;
     }
   }
+#else
+  if (rf_knob_wide_form == 1) return launch_w64<MODE, 0>(p, grid, st);
 #endif
   return launch_w16<MODE, 0>(p, grid, st);
 }

@@ -42,11 +42,13 @@ def main():
     lib = _lib.load_library()
     _lib.check(lib.rf_set_tuning(b"wide_sample_pairs", args.sample_pairs))
     # "dbg" or "dbg:ne" (ne = LDS-DMA pieces per phase of waves 0-3: 6 | 8 | 9 | 10 | 11, 0 = the product's 12; + 100 = with stamps)
-    variants = [tuple(int(y) for y in (x.split(":") + ["0"])[:2]) for x in args.dbgs.split(",")]
+    # third field: form (0 = eight waves x 32 queries, the round-2 kernel; 1 = four waves x 64 queries, round 3)
+    variants = [tuple(int(y) for y in (x.split(":") + ["0", "0"])[:3]) for x in args.dbgs.split(",")]
 
     def apply(v):
         _lib.check(lib.rf_set_tuning(b"wide_dbg", v[0]))
         _lib.check(lib.rf_set_tuning(b"wide_ne", v[1]))
+        _lib.check(lib.rf_set_tuning(b"wide_form", v[2]))
 
     ref = None
     for v in variants:
@@ -90,10 +92,10 @@ def main():
         st = [ix.search_profile(q, 10) for _ in range(20)]
         print("  stages (HIP events, us): " + "  ".join("%s %.1f" % (n, 1e3 * float(np.median([x[n] for x in st]))) for n in st[0]))
         ms = float(np.median(res[v]))
-        out["wide_dbg_%d_ne_%d" % v] = {"ms_per_step": round(ms, 5), "qps": round(args.batch / ms * 1e3, 1),
+        out["wide_dbg_%d_ne_%d_form_%d" % v] = {"ms_per_step": round(ms, 5), "qps": round(args.batch / ms * 1e3, 1),
                                      "corpus_GBps": round(args.rows * dim * 2 / ms / 1e6, 1)}
-        print("wide_dbg=%d ne=%d: %.1f us/step  %.0f QPS  %.0f GB/s" %
-              (v[0], v[1], ms * 1e3, args.batch / ms * 1e3, args.rows * dim * 2 / ms / 1e6))
+        print("wide_dbg=%d ne=%d form=%d: %.1f us/step  %.0f QPS  %.0f GB/s" %
+              (v[0], v[1], v[2], ms * 1e3, args.batch / ms * 1e3, args.rows * dim * 2 / ms / 1e6))
     print(json.dumps({"rows": args.rows, "batch": args.batch, "results": out}))
 
 

@@ -213,13 +213,21 @@ class Embedder:
         if self._small_done is not None:
             cur.wait_event(self._small_done)     # a previous caller on ANOTHER stream may still be using the buffers
         # rf_encode keys its cached hipGraphs on (B, T, buffers) and the tokenizer returns T = the longest row, so every
-        # query length would be a key of its own: round the width up to a multiple of 32 (padding changes no bit:
-        # tests/test_encoder_gpu.py::test_padding_content_and_width_are_ignored) -- at most 8 widths per batch size
-        Tr = min((T + 31) // 32 * 32, self.cfg["max_position"])
+        # query length would be a key of its own: round the width up (padding changes no bit:
+        # tests/test_encoder_gpu.py::test_padding_content_and_width_are_ignored) -- to a multiple of 8 up to 32 tokens
+        # (a lone query is 5-20 tokens: its forward should not grow to 32 rows), of 32 beyond: at most 11 widths per
+        # batch size.  Host ids are padded on the host (one upload, no extra launch); device ids with two small kernels.
+        Tr = (T + 7) // 8 * 8 if T <= 32 else (T + 31) // 32 * 32
+        Tr = min(Tr, self.cfg["max_position"])
         if Tr != T and B * Tr <= self.SMALL_SLOTS:
-            wide = sb["ids"][:B * Tr].view(B, Tr)
-            wide[:, :T].copy_(ids, non_blocking=True)
-            wide[:, T:].zero_()
+            if ids.device.type == "cpu":
+                padded = torch.zeros((B, Tr), dtype=torch.int32)
+                padded[:, :T] = ids
+                sb["ids"][:B * Tr].copy_(padded.view(-1), non_blocking=True)
+            else:
+                wide = sb["ids"][:B * Tr].view(B, Tr)
+                wide[:, :T].copy_(ids, non_blocking=True)
+                wide[:, T:].zero_()
             T = Tr
         else:
             sb["ids"][:B * T].copy_(ids.reshape(-1), non_blocking=True)

@@ -10,6 +10,7 @@ what separated it from the token-id path.  Host-side pools are therefore sized b
 """
 from __future__ import annotations
 
+import functools
 import math
 import os
 
@@ -34,8 +35,10 @@ def _cgroup_quota() -> float | None:
     return None
 
 
+@functools.lru_cache(maxsize=1)
 def cpu_budget() -> int:
-    """min(CPUs in the affinity mask, CFS quota rounded up), at least 1."""
+    """min(CPUs in the affinity mask, CFS quota rounded up), at least 1.  Read once per process (a 256-CPU
+    affinity mask and two cgroup files cost ~25 us per call: too much on the single-query path)."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:

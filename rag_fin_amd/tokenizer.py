@@ -249,6 +249,8 @@ class WordPieceTokenizer:
         import numpy as np
         if n_threads <= 0:
             n_threads = int(os.environ.get("RAGFIN_TOKENIZER_THREADS", "0") or 0)
+        if n_threads <= 0 and len(texts) < 64:
+            n_threads = 1        # a query-sized batch: no pool
         if n_threads <= 0:   # the CPUs the process may BURN (CFS quota), not the ones it may run on: hostcpu.py
             from .hostcpu import cpu_budget
             n_threads = min(cpu_budget(), 64)

@@ -176,7 +176,7 @@ __device__ __forceinline__ void gelu_slot(const f32x16& y, GeluTmp& g, uint32_t 
   } else if constexpr (w < 28) {
     constexpr int v = (w - 20) >> 1;
     if constexpr (((w - 20) & 1) == 0) g.p[v] = __builtin_amdgcn_exp2f(g.p[v]);
-    else g.r[v] = __builtin_amdgcn_fmed3f(y[4 * quad + v], 0.f, __builtin_inff());   // max(y, 0) in ONE operation (fmaxf costs a canonicalising v_max first)
+    else asm("v_max_f32 %0, 0, %1" : "=v"(g.r[v]) : "v"(y[4 * quad + v]));   // max(y, 0) in ONE operation (fmaxf and fmed3f(y, 0, inf) both compile to a canonicalising v_max + the v_max)
   } else if constexpr (w < 32) {
     constexpr int v = w - 28;
     g.p[v] = __builtin_fmaf(-__builtin_fabsf(y[4 * quad + v]), g.p[v], g.r[v]);
@@ -185,6 +185,36 @@ __device__ __forceinline__ void gelu_slot(const f32x16& y, GeluTmp& g, uint32_t 
     const half2v o = {(_Float16)g.p[2 * pr], (_Float16)g.p[2 * pr + 1]};
     hw[2 * quad + pr] = __builtin_bit_cast(uint32_t, o);
   }
+}
+
+// Which GELU slots ride in which MFMA gap of a full MLP step (48 gaps).  A gap hides about 24 cycles of issue beside
+// its MFMA (MI355X_MICROARCH.md, "single-issue instructions hidden per gap"), and the gaps are not alike: an even gap
+// also issues the two LDS reads of the pair three ahead (R cycles), every fourth one an LDS-DMA piece (s_mov m0 +
+// s_nop + the load: D cycles).  A v_exp_f32 slot costs 8 cycles, every other slot 4.  The slots keep their order;
+// the table gives each gap the slots that fit b - (its fixed cost), with the smallest b for which all 136 are placed
+// -- the spread that overflows no gap if any does not.  (Uniform 2.83 slots per gap: the LDS-DMA gaps ran over.)
+struct GeluSched {
+  int start[49];
+};
+__host__ __device__ constexpr int gelu_slot_cost(int O) {
+  const int w = O % 34;
+  return (w >= 20 && w < 28 && ((w - 20) & 1) == 0) ? 8 : 4;
+}
+__host__ __device__ constexpr GeluSched gelu_sched(int R, int D) {
+  GeluSched s{};
+  for (int b = 4; b < 4096; b += 2) {
+    int o = 0;
+    for (int n = 0; n < 48; ++n) {
+      s.start[n] = o;
+      const int fixed = ((n & 1) == 0 ? R : 0) + ((n & 3) == 3 ? D : 0);
+      int used = 0;
+      while (o < GELU_SLOTS && used + gelu_slot_cost(o) <= b - fixed) used += gelu_slot_cost(o++);
+    }
+    s.start[48] = GELU_SLOTS;
+    if (o == GELU_SLOTS) return s;
+  }
+  for (int n = 0; n <= 48; ++n) s.start[n] = n * GELU_SLOTS / 48;   // (not reached)
+  return s;
 }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -227,10 +257,20 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   // (inline asm: hipcc's builtin took the source as a per-lane 64-bit address -- one v_lshl_add_u64 per piece in
   // a kernel bound by its VALU issue -- and every compiler-visible LDS read after it drew an s_waitcnt vmcnt(0).
   // All LDS-DMA of this kernel is asm, so the compiler never holds anything in M0 across these statements.)
-  auto issue_piece = [&](const char* src_step, uint32_t dst_step, int p) __attribute__((always_inline)) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :: "s"(dst_step + (uint32_t)p * 1024u), "v"(lane_off), "s"(src_step + (size_t)p * 1024) : "memory");
+  // One wave per SIMD issues one instruction per 4-cycle slot, scalar ones included.  The instruction's immediate
+  // offset is added to BOTH addresses (global source and LDS destination), so a group of four pieces shares one
+  // source base and one M0: s_mov m0, s_nop, load -- three instructions per piece where s_add, s_add / s_addc,
+  // s_mov, s_nop, load were six.  (M0 is still written for every piece: nothing here relies on the compiler
+  // leaving it alone between two asm statements.)
+  auto issue_piece = [&](const char* src_step, uint32_t dst_step, auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+    const char* const base = src_step + (size_t)(p >> 2) * 4096;
+    const uint32_t dbase = dst_step + (uint32_t)(p >> 2) * 4096u;
+    const uint32_t lo = lane_off;   // (a generic lambda does not capture a variable named only in an asm operand)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                 :: "s"(dbase), "v"(lo), "s"(base), "n"((p & 3) * 1024) : "memory");
   };
+  using PC0 = std::integral_constant<int, 0>;
   auto step_src = [&](int S) __attribute__((always_inline)) {
     return ring_src + (size_t)(S < n_steps ? S : 0) * (PB_FRAGS * 1024);
   };
@@ -253,12 +293,10 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   for (int q = 0; q < 4; ++q) {
     const int f = wave + 4 * q;   // parameter fragment (15 of them)
     if (f < PB_PARAM_FRAGS)
-      issue_piece((const char*)a.pack + (size_t)f * 1024, slots_s + (uint32_t)((PB_SLOTS * PB_FRAGS + f) * 1024), 0);
+      issue_piece((const char*)a.pack + (size_t)f * 1024, slots_s + (uint32_t)((PB_SLOTS * PB_FRAGS + f) * 1024), PC0{});
   }
-#pragma unroll
-  for (int p = 0; p < PB_PW; ++p) issue_piece(step_src(0), step_dst(0), p);
-#pragma unroll
-  for (int p = 0; p < PB_PW; ++p) issue_piece(step_src(1), step_dst(1), p);
+  static_for<0, PB_PW>([&](auto pc) __attribute__((always_inline)) { issue_piece(step_src(0), step_dst(0), pc); });
+  static_for<0, PB_PW>([&](auto pc) __attribute__((always_inline)) { issue_piece(step_src(1), step_dst(1), pc); });
   const int M = *a.m_ptr;
   if (t0 >= M) {   // whole workgroup; its LDS-DMA pieces must land before the LDS is handed on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -328,7 +366,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
     run_step<PB_FRAGS>([](int m) constexpr { return m; }, sa, [&](auto Mc, const rf_u32x4& af) __attribute__((always_inline)) {
       constexpr int m = decltype(Mc)::value, fb = m % 12, kk = 4 * S + m / 12;
       acc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, xf[kk]), acc[fb], 0, 0, 0);
-      if constexpr ((m & 3) == 3) issue_piece(nsrc, ndst, m >> 2);
+      if constexpr ((m & 3) == 3) issue_piece(nsrc, ndst, std::integral_constant<int, (m >> 2)>{});
       if constexpr (m % 6 == 5 && S < PB_STEPS_A - 1) {
         constexpr int q = 8 * S + m / 6;   // 0..39
         if constexpr (q < 16) gload16(xf[8 + q], csrc + (size_t)(8 + q) * 512);
@@ -417,8 +455,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
     if constexpr (decltype(qb_c)::value) {
       const char* const qb = (const char*)a.pack + ((size_t)16 + PB_RING_FRAGS) * 1024;
       const uint32_t b1_s = slots_s + (uint32_t)(PB_SLOTS * PB_FRAGS * 1024);
-      issue_piece(qb + (size_t)wave * 1024, b1_s + (uint32_t)wave * 1024u, 0);
-      issue_piece(qb + 4 * 1024, b1_s + 4u * 1024u, 0);
+      issue_piece(qb + (size_t)wave * 1024, b1_s + (uint32_t)wave * 1024u, PC0{});
+      issue_piece(qb + 4 * 1024, b1_s + 4u * 1024u, PC0{});
     }
     const uint32_t sa = slots_a + (uint32_t)((S % PB_SLOTS) * PB_FRAGS * 1024);
     const char* const nsrc = step_src(S + 2);
@@ -460,7 +498,11 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
         }
       }
       if constexpr (GE) {   // GELU of block i - 1 (accumulator and h of the other parity): this gap's slots
-        constexpr int o0 = n * GELU_SLOTS / NM, o1 = (n + 1) * GELU_SLOTS / NM;
+        // (R, D) = (4, 24) measured: 2 151 cycles per step against 2 207 for the uniform spread (ABL 32); (4, 12) 2 218,
+        // (0, 8) 2 191, (8, 16) 2 224, (0, 24) 2 217, (8, 32) 2 221, (12, 36) 2 212 -- no slot in an LDS-DMA gap is what counts
+        constexpr GeluSched sched = gelu_sched(4, 24);
+        constexpr bool uniform = NM != 48 || (ABL & 32);
+        constexpr int o0 = uniform ? n * GELU_SLOTS / NM : sched.start[n], o1 = uniform ? (n + 1) * GELU_SLOTS / NM : sched.start[n + 1];
         static_for<o0, o1>([&](auto Oc) __attribute__((always_inline)) {
           gelu_slot<decltype(Oc)::value>(acc1[PAR ^ 1], gt, hw[PAR ^ 1]);
         });
@@ -468,9 +510,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
       if constexpr (!(ABL & 1)) {
         // 12 pieces per step whatever the step holds: one per four MFMAs, or one per two where the step has 24
         if constexpr (NM == 48) {
-          if constexpr ((n & 3) == 3) issue_piece(nsrc, ndst, n >> 2);
+          if constexpr ((n & 3) == 3) issue_piece(nsrc, ndst, std::integral_constant<int, (n >> 2)>{});
         } else {
-          if constexpr ((n & 1) == 1) issue_piece(nsrc, ndst, n >> 1);
+          if constexpr ((n & 1) == 1) issue_piece(nsrc, ndst, std::integral_constant<int, (n >> 1)>{});
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -603,7 +645,7 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
           constexpr int o0 = m * 28 / PB_FRAGS, o1 = (m + 1) * 28 / PB_FRAGS;
           static_for<o0, o1>([&](auto Oc) __attribute__((always_inline)) { epi_slot(Oc, qa[PAR ^ 1], 2 * t - 2); });
         }
-        if constexpr ((m & 3) == 3) issue_piece(nsrc, ndst, m >> 2);
+        if constexpr ((m & 3) == 3) issue_piece(nsrc, ndst, std::integral_constant<int, (m >> 2)>{});
         __builtin_amdgcn_sched_barrier(0);
       });
     };
@@ -641,9 +683,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
 int rf_launch_post_block(const rf_post_args& a_in, int token_slots, hipStream_t st) {
   rf_post_args a = a_in;
 #ifdef RF_EXPERIMENTS
-  if (a.abl & 32) {   // stamps of the launches WITH the QKV phase only (the last layer's launch has none and would overwrite them)
+  if (a.abl & 256) {   // stamps of the launches WITH the QKV phase only (the last layer's launch has none and would overwrite them)
     if (!a.qkv_out) a.dbg = nullptr;
-    a.abl &= ~32;
+    a.abl &= ~256;
   }
 #endif
   const dim3 grid((token_slots + PB_TOK - 1) / PB_TOK), block(PB_WAVES * 64);
@@ -664,6 +706,7 @@ int rf_launch_post_block(const rf_post_args& a_in, int token_slots, hipStream_t 
       case 8: RF_PB_LAUNCH(1, 8);
       case 4: RF_PB_LAUNCH(1, 4);
       case 16: RF_PB_LAUNCH(1, 16);
+      case 32: RF_PB_LAUNCH(1, 32);
       default: RF_PB_LAUNCH(1, 0);
     }
   }

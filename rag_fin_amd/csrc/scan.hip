@@ -233,7 +233,7 @@ extern "C" int rf_set_tuning(const char* key, int value) {
                     {"wide_dbg", &rf_knob_wide_dbg, 0, 127}, {"wide_ne", &rf_knob_wide_ne, 0, 112}, {"wide_form", &rf_knob_wide_form, 0, 1}, {"linear_dma", &rf_knob_linear_dma, 0, 3},
                     {"linear_small", &rf_knob_linear_small, 0, 1}, {"k384_ntb", &rf_knob_k384_ntb, 2, 4},
                     {"ffn2_ntb", &rf_knob_ffn2_ntb, 2, 4}, {"gemm_tile", &rf_knob_gemm_tile, 0, 15}, {"encode_graph", &rf_knob_encode_graph, 0, 1},
-                    {"linear_dbg", &rf_knob_linear_dbg, 0, 63}, {"debug_epi", &rf_knob_debug_epi, 0, 5}, {"post_block", &rf_knob_post_block, 0, 1}, {"post_dbg", &rf_knob_post_dbg, 0, 63}, {"post_qkv", &rf_knob_post_qkv, 0, 1}, {"att_heads", &rf_knob_att_heads, 1, 2}, {"one_query", &rf_knob_one_query, 0, 1}, {"gemm_tile_dma", &rf_knob_gemm_tile_dma, 0, 2}};
+                    {"linear_dbg", &rf_knob_linear_dbg, 0, 63}, {"debug_epi", &rf_knob_debug_epi, 0, 5}, {"post_block", &rf_knob_post_block, 0, 1}, {"post_dbg", &rf_knob_post_dbg, 0, 511}, {"post_qkv", &rf_knob_post_qkv, 0, 1}, {"att_heads", &rf_knob_att_heads, 1, 2}, {"one_query", &rf_knob_one_query, 0, 1}, {"gemm_tile_dma", &rf_knob_gemm_tile_dma, 0, 2}};
   for (const K& k : keys)
     if (!strcmp(key, k.name) && value >= k.lo && value <= k.hi) {
       if (k.var == &rf_knob_ring24 && value != 6 && value != 8 && value != 12 && value != 24) break;

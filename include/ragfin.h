@@ -50,6 +50,7 @@ extern "C" {
 
 typedef struct rf_index rf_index_t;
 typedef struct rf_encoder rf_encoder_t;
+typedef struct rf_comm rf_comm_t;      /* one rank's membership of a sharded search job (RCCL communicator) */
 
 /* ---- library ---------------------------------------------------------- */
 int rf_version(void);
@@ -160,6 +161,39 @@ int rf_merge_shards_packed(const int64_t* packed_dev, int W, int B, int k,
  * (rf_search, rf_map_ids, ncclAllGather, rf_merge_shards_packed) and no host library touches
  * the ids.  New in this build; stands beside vector_rag_mcp/main.py:51-57. */
 int rf_map_ids(int64_t* ids_dev, int64_t n, const int64_t* id_map_dev, int64_t n_map, void* stream);
+/* ---- the sharded step as ONE call (rf_comm_init / rf_search_sharded; 8e) ----------
+ * One process per GPU; rank r holds a row shard in its rf_index_t.  The reference has no counterpart
+ * (one Milvus server answers vector_rag_mcp/main.py:51-57); this is what stands in for it at N > 1.
+ *   rf_comm_unique_id   rank 0 draws the job's 128-byte id (RF_COMM_ID_BYTES, host memory); the HOST
+ *                       ships it to the other ranks (MPI, a socket, torch.distributed, a file)
+ *   rf_comm_init        every rank: ncclCommInitRank on `device` -- blocks until all `world` ranks arrive
+ *   rf_search_sharded   every rank, same B and k, calls in the same order on all ranks: rf_search into
+ *                       the packed send buffer, rf_map_ids when id_map_dev is given (id_base is then
+ *                       ignored), ncclAllGather of rf_packed_shard_words(B, k) words, rf_merge_shards_packed.
+ *                       Four enqueues on `stream`, no host synchronisation; scores_dev / ids_dev hold the
+ *                       GLOBAL top-k on every rank, flags_dev (nullable) the OR of the shards' RF_FLAG_*
+ *                       bits -- a flagged query is re-run through rf_search_exhaustive on every shard and
+ *                       merged again by the host, exactly as for one GPU.
+ *                       scratch_dev: rf_search_sharded_scratch_words(comm, B, k) int64 words of device
+ *                       memory owned by the caller, not shared between steps that may be in flight together.
+ * One collective at a time per communicator: the caller serialises rf_search_sharded calls on one rf_comm_t
+ * (different streams are fine as long as every rank enqueues them in the same order).
+ * RCCL is bound at run time (dlopen of librccl.so, or RAGFIN_RCCL_PATH; a copy the process has already
+ * loaded is reused): where it is absent these calls return RF_ERR_UNSUPPORTED and the rest of the
+ * library works.  rag_fin_amd/sharded.py runs the same four enqueues from Python (rag_fin_amd/rccl.py
+ * binds the same library). */
+#define RF_COMM_ID_BYTES 128
+int rf_comm_unique_id(void* id_out);
+int rf_comm_init(int rank, int world, const void* id, int device, rf_comm_t** out);
+int rf_comm_destroy(rf_comm_t* comm);
+int rf_comm_rank(const rf_comm_t* comm);
+int rf_comm_world(const rf_comm_t* comm);
+size_t rf_search_sharded_scratch_words(const rf_comm_t* comm, int B, int k);
+int rf_search_sharded(const rf_index_t* ix, rf_comm_t* comm, const void* q_dev, int B, int k,
+                      int64_t id_base, const int64_t* id_map_dev, int64_t n_map,
+                      float* scores_dev, int64_t* ids_dev, uint32_t* flags_dev,
+                      void* workspace_dev, size_t workspace_bytes,
+                      int64_t* scratch_dev, size_t scratch_words, void* stream);
 /* Test hook: raw MFMA scan scores fp32 [B, n] for the first n rows. */
 int rf_debug_scores(const rf_index_t* ix, const void* q_dev, int B, int64_t n,
                     float* out_dev, void* stream);

@@ -70,6 +70,14 @@ SIGNATURES = {
     "rf_packed_shard_words": (c_size_t, [c_int, c_int]),
     "rf_merge_shards_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rf_map_ids": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "rf_comm_unique_id": (c_int, [c_void_p]),
+    "rf_comm_init": (c_int, [c_int, c_int, c_void_p, c_int, POINTER(c_void_p)]),
+    "rf_comm_destroy": (c_int, [c_void_p]),
+    "rf_comm_rank": (c_int, [c_void_p]),
+    "rf_comm_world": (c_int, [c_void_p]),
+    "rf_search_sharded_scratch_words": (c_size_t, [c_void_p, c_int, c_int]),
+    "rf_search_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "rf_tokenizer_create": (c_int, [POINTER(c_void_p), c_char_p, c_size_t, c_int, c_int]),
     "rf_tokenizer_destroy": (c_int, [c_void_p]),
     "rf_tokenizer_set_punctuation": (c_int, [c_void_p, c_void_p, c_int]),

@@ -28,7 +28,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libragfin_hip.so"
 LIB_PATH = os.path.join(CSRC, LIB_NAME)
 EXP_LIB_PATH = os.path.join(CSRC, "libragfin_hip_exp.so")
-SOURCES = ["index.hip", "scan.hip", "scan_wide.hip", "merge.hip", "api.hip", "encoder.hip", "encoder_post.hip", "tokenizer.cpp"]
+SOURCES = ["index.hip", "scan.hip", "scan_wide.hip", "merge.hip", "api.hip", "comm.hip", "encoder.hip", "encoder_post.hip", "tokenizer.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -138,7 +138,7 @@ def _build_lib_locked(force: bool, verbose: bool, experiments: bool) -> str:
             f.write(digest)
         relink = True
     if relink:
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, id_obj])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, id_obj, "-ldl"])
     with open(out + ".id", "w") as f:   # sidecar: lets the loader decide without dlopen-ing a stale library
         f.write(digest)
     return out

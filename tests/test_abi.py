@@ -40,6 +40,14 @@ def test_host_side_argument_checks_need_no_gpu():
     assert lib.rf_index_storage_bytes(384, 0) == 0
     assert lib.rf_search_workspace_bytes(None) > 4 * 1024 * 1024
     assert lib.rf_index_size(None) == -1
+    # the sharded step's entry points check their arguments before they look for RCCL
+    import ctypes
+    comm = ctypes.c_void_p()
+    assert lib.rf_comm_init(2, 2, ctypes.create_string_buffer(128), 0, ctypes.byref(comm)) == -1   # rank >= world
+    assert lib.rf_comm_init(0, 1, None, 0, ctypes.byref(comm)) == -1 and not comm.value
+    assert lib.rf_comm_rank(None) == -1 and lib.rf_comm_world(None) == 0 and lib.rf_comm_destroy(None) == 0
+    assert lib.rf_search_sharded_scratch_words(None, 64, 10) == 0
+    assert lib.rf_search_sharded(None, None, None, 64, 10, 0, None, 0, None, None, None, None, 0, None, 0, None) == -1
 
 
 def test_product_fails_loudly_without_gpu():

@@ -269,3 +269,78 @@ def test_id_table_is_applied_on_the_device_in_every_step_form(gpu_device):
         _lib.check(ix.lib.rf_map_ids(c_void_p(ids.data_ptr()), ids.numel(), c_void_p(table.data_ptr()), n,
                                      _lib.current_stream_ptr()))
     assert ids.cpu().tolist() == [int(gid[0]), int(gid[4999]), -1, -1, int(gid[17])]
+
+
+def test_native_sharded_step_behind_the_c_abi(gpu_device):
+    """rf_comm_init + rf_search_sharded (include/ragfin.h): the whole step -- scan into the packed
+    send buffer, id table, ncclAllGather, merge -- as ONE C call with no Python in it.  One rank here (a card
+    cannot host two RCCL ranks): the collective is still issued (a rank gathering from itself), so the calls N
+    ranks would make are the calls this test makes.  Answers = the C oracle's; ids through id_base and through
+    an id table; a duplicate-heavy corpus raises the same flags rf_search raises."""
+    import ctypes
+    import torch
+    from ctypes import byref, c_void_p
+    from rag_fin_amd import _lib
+    from rag_fin_amd.store import GpuIndex
+    n, d, b, k = 30_000, 384, 64, 10
+    c = osearch.synth_unit_rows(n, d, 77)
+    q16 = osearch.synth_unit_rows(b, d, 78)
+    ix = GpuIndex(d, n, gpu_device)
+    ix.add(torch.from_numpy(c).to(gpu_device))
+    q = torch.from_numpy(q16).to(gpu_device)
+    lib = ix.lib
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(lib.rf_comm_unique_id(uid))
+    comm = c_void_p()
+    _lib.check(lib.rf_comm_init(0, 1, uid, gpu_device.index or 0, byref(comm)))
+    try:
+        assert lib.rf_comm_rank(comm) == 0 and lib.rf_comm_world(comm) == 1
+        words = int(lib.rf_search_sharded_scratch_words(comm, b, k))
+        assert words == 2 * int(lib.rf_packed_shard_words(b, k)) + (b * k + 1) // 2
+        scratch = torch.empty(words, dtype=torch.int64, device=gpu_device)
+        scores = torch.empty((b, k), dtype=torch.float32, device=gpu_device)
+        ids = torch.empty((b, k), dtype=torch.int64, device=gpu_device)
+        flags = torch.empty((b,), dtype=torch.int32, device=gpu_device)
+        ws = ix.new_workspace()
+        st = torch.cuda.Stream(device=gpu_device)
+        torch.cuda.synchronize(gpu_device)
+
+        def step(id_base, table):
+            with torch.cuda.device(gpu_device):
+                _lib.check(lib.rf_search_sharded(
+                    ix.handle, comm, c_void_p(q.data_ptr()), b, k, id_base,
+                    c_void_p(table.data_ptr()) if table is not None else None, table.numel() if table is not None else 0,
+                    c_void_p(scores.data_ptr()), c_void_p(ids.data_ptr()), c_void_p(flags.data_ptr()),
+                    c_void_p(ws.data_ptr()), ix.workspace_bytes, c_void_p(scratch.data_ptr()), words,
+                    c_void_p(st.cuda_stream)))
+            st.synchronize()
+            return scores.cpu().numpy().copy(), ids.cpu().numpy().copy(), flags.cpu().numpy().copy()
+
+        os_, oi = c_oracle.search(q16, c, k)
+        s, i, f = step(1_000_000, None)
+        assert np.array_equal(i, oi + 1_000_000) and np.array_equal(s, os_.astype(np.float32)) and not f.any()
+        gid = np.random.default_rng(1).permutation(10 * n)[:n].astype(np.int64)
+        table = torch.from_numpy(gid).to(gpu_device)
+        s, i, f = step(123, table)                      # id_base is ignored when a table is given
+        assert np.array_equal(i, gid[oi]) and np.array_equal(s, os_.astype(np.float32)) and not f.any()
+        # argument checks come back as codes, not faults
+        assert lib.rf_search_sharded(ix.handle, comm, c_void_p(q.data_ptr()), b, k, 0, None, 0, c_void_p(scores.data_ptr()),
+                                     c_void_p(ids.data_ptr()), None, c_void_p(ws.data_ptr()), ix.workspace_bytes,
+                                     c_void_p(scratch.data_ptr()), words - 1, c_void_p(st.cuda_stream)) == -3   # RF_ERR_CAPACITY
+        assert lib.rf_search_sharded(ix.handle, comm, c_void_p(q.data_ptr()), b, k, 0, c_void_p(table.data_ptr()), 0,
+                                     c_void_p(scores.data_ptr()), c_void_p(ids.data_ptr()), None, c_void_p(ws.data_ptr()),
+                                     ix.workspace_bytes, c_void_p(scratch.data_ptr()), words, c_void_p(st.cuda_stream)) == -1
+        # the same flags as rf_search on data built to overflow the candidate lists: every row the same vector
+        dup = np.repeat(c[:1], n, axis=0)
+        ix2 = GpuIndex(d, n, gpu_device)
+        ix2.add(torch.from_numpy(dup).to(gpu_device))
+        _, _, _, f_local = ix2.search_raw(q, k, want_exact=True)
+        with torch.cuda.device(gpu_device):
+            _lib.check(lib.rf_search_sharded(ix2.handle, comm, c_void_p(q.data_ptr()), b, k, 0, None, 0,
+                                             c_void_p(scores.data_ptr()), c_void_p(ids.data_ptr()), c_void_p(flags.data_ptr()),
+                                             c_void_p(ws.data_ptr()), ix2.workspace_bytes, c_void_p(scratch.data_ptr()), words,
+                                             c_void_p(st.cuda_stream)))
+        st.synchronize()
+        assert torch.equal(flags, f_local.to(torch.int32))
+    finally:
+        _lib.check(lib.rf_comm_destroy(comm))

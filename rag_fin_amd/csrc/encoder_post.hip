@@ -472,6 +472,9 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
     // MFMA gap n of the step -> its A fragment.  In a full step the two GEMMs ALTERNATE (n even: FFN2 number n / 2,
     // n odd: FFN1 k-step n / 2), so that a pair of LDS reads feeds one MFMA of each accumulation chain.
     auto frag_of = [](int n) constexpr { return (F2 && F1) ? ((n & 1) ? (n >> 1) : 24 + (n >> 1)) : (F2 ? 24 + n : n); };
+    // (Probes of round 3, taken out again: pairs read four / five ahead instead of three 2 117 / 2 172 cycles per step against
+    // 2 107; no wait for the reads at all 2 083; FFN1 on two accumulation chains 2 113 -- neither the LDS latency nor the
+    // FFN1 chain is what the step waits for.)
     run_step<NM>(frag_of, sa, [&](auto Nc, const rf_u32x4& afr) __attribute__((always_inline)) {
       constexpr int n = decltype(Nc)::value;             // MFMA gap of the step
       constexpr int fr = frag_of(n);

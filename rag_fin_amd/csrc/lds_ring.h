@@ -67,26 +67,26 @@ template <int N>
 __device__ __forceinline__ void lds_wait_pair(rf_u32x4 (&d)[2]) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(d[0]), "+v"(d[1]) : "n"(N));
 }
-template <int NM, class FragOf, class Body>
+template <int NM, int AHEAD = 3, bool NOWAIT = false, class FragOf, class Body>
 __device__ __forceinline__ void run_step(FragOf frag_of, uint32_t sa, Body&& body) {
   constexpr int NP = NM / 2;   // pairs
-  rf_u32x4 fa[4][2];
+  constexpr int NB = AHEAD + 1;
+  rf_u32x4 fa[NB][2];
   auto read_pair = [&](auto Gc) __attribute__((always_inline)) {
     constexpr int G = decltype(Gc)::value;
-    lds_read_frag<frag_of(2 * G)>(fa[G & 3][0], sa);
-    lds_read_frag<frag_of(2 * G + 1)>(fa[G & 3][1], sa);
+    lds_read_frag<frag_of(2 * G)>(fa[G % NB][0], sa);
+    lds_read_frag<frag_of(2 * G + 1)>(fa[G % NB][1], sa);
   };
-  static_for<0, (NP < 3 ? NP : 3)>([&](auto Gc) __attribute__((always_inline)) { read_pair(Gc); });
+  static_for<0, (NP < AHEAD ? NP : AHEAD)>([&](auto Gc) __attribute__((always_inline)) { read_pair(Gc); });
   static_for<0, NP>([&](auto Gc) __attribute__((always_inline)) {
     constexpr int G = decltype(Gc)::value;
-    // pair G + 3 is read BEHIND the pair's first MFMA (its two issue slots sit in that MFMA's shadow, not in front
-    // of it together with the previous gap's vector work and LDS-DMA piece): pairs read after pair G at its wait = 2
-    constexpr int newer = (NP - 1 - G) < 2 ? (NP - 1 - G) : 2;
-    lds_wait_pair<2 * newer>(fa[G & 3]);
-    body(std::integral_constant<int, 2 * G>{}, fa[G & 3][0]);
-    if constexpr (G + 3 < NP) read_pair(std::integral_constant<int, G + 3>{});
-    body(std::integral_constant<int, 2 * G + 1>{}, fa[G & 3][1]);
+    // pair G + AHEAD is read BEHIND the pair's first MFMA (its two issue slots sit in that MFMA's shadow, not in front
+    // of it together with the previous gap's vector work and LDS-DMA piece): pairs read after pair G at its wait = AHEAD - 1
+    constexpr int newer = (NP - 1 - G) < (AHEAD - 1) ? (NP - 1 - G) : (AHEAD - 1);
+    if constexpr (NOWAIT) asm volatile("" : "+v"(fa[G % NB][0]), "+v"(fa[G % NB][1]));
+    else lds_wait_pair<2 * newer>(fa[G % NB]);
+    body(std::integral_constant<int, 2 * G>{}, fa[G % NB][0]);
+    if constexpr (G + AHEAD < NP) read_pair(std::integral_constant<int, G + AHEAD>{});
+    body(std::integral_constant<int, 2 * G + 1>{}, fa[G % NB][1]);
   });
 }
-
-

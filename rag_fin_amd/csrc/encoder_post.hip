@@ -512,6 +512,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
       }
       if constexpr (!(ABL & 1)) {
         // 12 pieces per step whatever the step holds: one per four MFMAs, or one per two where the step has 24
+        // (the 12 pieces as three groups of four behind one M0 write -- 18 instructions fewer -- measured 2 187 cycles per step
+        // against 2 107: four loads in one gap overflow it)
         if constexpr (NM == 48) {
           if constexpr ((n & 3) == 3) issue_piece(nsrc, ndst, std::integral_constant<int, (n >> 2)>{});
         } else {

@@ -359,7 +359,12 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
   // step's 12 pieces AND its 8 loads stay in flight.)
   static_for<0, PB_STEPS_A>([&](auto Sc) __attribute__((always_inline)) {
     constexpr int S = decltype(Sc)::value;
-    sync_step(std::integral_constant<int, (S >= 1 ? 8 : 0)>{});
+    // LPS loads per step, one after every (48 / LPS)-th MFMA, until the 40 are out.  (12 / 16 per step only move the time
+    // into the first steps -- 3 240 3 820 4 044 2 740 1 760 1 696 and 4 084 4 568 3 344 1 748 1 696 1 696 cycles against
+    // 2 032 2 672 2 488 2 576 2 632 1 828: the phase waits for HBM either way, and a step without loads is 1 696.)
+    constexpr int LPS = 8;
+    constexpr int prev_loads = S == 0 ? 0 : (40 - LPS * (S - 1) < 0 ? 0 : (40 - LPS * (S - 1) < LPS ? 40 - LPS * (S - 1) : LPS));
+    sync_step(std::integral_constant<int, prev_loads>{});
     const uint32_t sa = slots_a + (uint32_t)((S % PB_SLOTS) * PB_FRAGS * 1024);
     const char* const nsrc = step_src(S + 2);
     const uint32_t ndst = step_dst(S + 2);
@@ -367,8 +372,8 @@ __global__ void __launch_bounds__(PB_WAVES * 64, 1) RF_NO_PACKED_FP32 k_post_blo
       constexpr int m = decltype(Mc)::value, fb = m % 12, kk = 4 * S + m / 12;
       acc[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, af), __builtin_bit_cast(half8, xf[kk]), acc[fb], 0, 0, 0);
       if constexpr ((m & 3) == 3) issue_piece(nsrc, ndst, std::integral_constant<int, (m >> 2)>{});
-      if constexpr (m % 6 == 5 && S < PB_STEPS_A - 1) {
-        constexpr int q = 8 * S + m / 6;   // 0..39
+      if constexpr (m % (48 / LPS) == 48 / LPS - 1 && LPS * S + m / (48 / LPS) < 40) {
+        constexpr int q = LPS * S + m / (48 / LPS);   // 0..39
         if constexpr (q < 16) gload16(xf[8 + q], csrc + (size_t)(8 + q) * 512);
         else gload16(xr[q - 16], rsrc + (size_t)(q - 16) * 512);
       }

@@ -263,7 +263,13 @@ size_t rf_encode_workspace_bytes(const rf_encoder_t* enc, int B, int T);
  * (rag_fin_amd.embedder does).
  * ids_dev int32 [B, T] (padded), lens_dev int32 [B] (valid tokens per row).
  * out_f16_dev fp16 [B, H] and/or out_f32_dev fp32 [B, H] (either nullable):
- * masked mean-pool + L2-normalise of the last hidden state. */
+ * masked mean-pool + L2-normalise of the last hidden state.
+ * T <= max_position (RF_ERR_INVALID beyond).  T <= 256 -- the reference model's max_seq_length,
+ * vector_rag_mcp/main.py:41 -- runs the MFMA attention; 256 < T <= max_position is supported and
+ * tested (tests/test_encoder_gpu.py, T = 257, 300, 384, 512 against the fp64 oracle at the same
+ * tolerances) but takes a scalar attention kernel: correct, several times slower per token.
+ * Batches of >= 8192 token slots take the fused per-layer path (csrc/encoder_post.hip); the cached
+ * hipGraphs are an LRU of 32 entries, an evicted one is destroyed after its last launch has finished. */
 int rf_encode(const rf_encoder_t* enc, const int32_t* ids_dev, const int32_t* lens_dev,
               int B, int T, void* out_f16_dev, float* out_f32_dev,
               void* workspace_dev, size_t workspace_bytes, void* stream);

@@ -25,7 +25,7 @@
 //     LDS ring by LDS-DMA, 48 KiB per step, two steps ahead behind a counted vmcnt and one raw
 //     s_barrier per step; all four waves read every fragment (one ds_read_b128 per MFMA).
 //   * MLP step i = { FFN2 of block i - 2 (24 MFMAs), FFN1 of block i (24 MFMAs) } with the GELU of
-//     block i - 1 cut into the 48 MFMA gaps (5.3 plain VALU operations per gap): the slot of step i
+//     block i - 1 cut into 136 single operations placed in the MFMA gaps by a cost table (gelu_sched): the slot of step i
 //     holds W1[block i] and the W2 columns of block i - 2.
 // Registers: acc2 192 + activations 96 + two FFN1 accumulators 32 + two h operands 16 + LDS read
 // groups 32 + GELU temporaries ~16.

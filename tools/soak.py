@@ -51,7 +51,7 @@ def main():
     cfg = dict(oenc.MINILM_L6)
     emb = Embedder(oenc.random_weights(cfg, 0), cfg, device=dev)
     rng = np.random.default_rng(1)
-    ebad = 0
+    ebad, worst = 0, 0.0
     for it in range(args.encode_iters):
         B, T = 240, 256                                  # 61 440 slots: 256-token LDS-DMA workgroups
         lens = rng.integers(40, T + 1, B).astype(np.int32)
@@ -59,13 +59,21 @@ def main():
         a = emb.encode_ids(ids, lens, out_dtype="float32")
         b = emb.encode_ids(ids, lens, out_dtype="float32")
         ok = torch.equal(a, b)
-        if it % 10 == 0:
-            _lib.check(lib.rf_set_tuning(b"linear_dma", 0))
+        if it % 10 == 0:   # independent path: the five-launch layer (no k_post_block), then that with the direct-load GEMMs
+            _lib.check(lib.rf_set_tuning(b"post_block", 0))
             d = emb.encode_ids(ids, lens, out_dtype="float32")
+            _lib.check(lib.rf_set_tuning(b"linear_dma", 0))
+            d2 = emb.encode_ids(ids, lens, out_dtype="float32")
             _lib.check(lib.rf_set_tuning(b"linear_dma", 1))
-            ok = ok and float((a - d).abs().max()) < 2e-3
+            _lib.check(lib.rf_set_tuning(b"post_block", 1))
+            diff = max(float((a - d).abs().max()), float((a - d2).abs().max()))
+            worst = max(worst, diff)
+            ok = ok and diff < 1e-3 and bool(torch.isfinite(a).all())
         ebad += 0 if ok else 1
-    print(f"encoder (LDS-DMA GEMMs): {args.encode_iters} iterations, {ebad} mismatches")
+        if it % 250 == 0:
+            print(f"encode iter {it}: mismatches so far {ebad}, largest difference to the other paths {worst:.2e}", flush=True)
+    print(f"encoder (k_post_block + LDS-DMA GEMMs): {args.encode_iters} iterations, {ebad} mismatches, "
+          f"largest difference to the five-launch / direct-load paths {worst:.2e}")
     sys.exit(1 if (bad or ebad) else 0)
 
 

@@ -46,6 +46,13 @@ __global__ void __launch_bounds__(256, 1) k(const u32x4* __restrict__ w, const u
       const u32x4 a = lds[f * 64 + lane];
       if (SHAPE == 0) {
         acc32[f & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b[f % KS]), acc32[f & 3], 0, 0, 0);
+      } else if (SHAPE == 2) {   // 32x32x16, the fragment used for TWO token blocks (64 tokens per wave): half the LDS bytes per FLOP
+        acc32[f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b[f % KS]), acc32[f & 1], 0, 0, 0);
+        acc32[2 + (f & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b[(f + 5) % KS]), acc32[2 + (f & 1)], 0, 0, 0);
+      } else if (SHAPE == 3) {   // 16x16x32, the fragment used for FOUR token tiles (64 tokens per wave)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc16[(4 * f + t) & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b[(f + 5 * t) % KS]), acc16[(4 * f + t) & 15], 0, 0, 0);
       } else {
         acc16[(2 * f) & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b[f % KS]), acc16[(2 * f) & 15], 0, 0, 0);
         acc16[(2 * f + 1) & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b[(f + 7) % KS]), acc16[(2 * f + 1) & 15], 0, 0, 0);
@@ -93,7 +100,7 @@ static void run(const char* name, const u32x4* w, const u32x4* x, float* out, fl
   }
   std::sort(clk.begin(), clk.end());
   std::sort(cyc.begin(), cyc.end());
-  const double flop = (double)reps * cus * 4 * (double)steps * FRAGS * 32768.0;
+  const double flop = (double)reps * cus * 4 * (double)steps * FRAGS * 32768.0 * (SHAPE >= 2 ? 2.0 : 1.0);
   printf("%-44s %7.1f TFLOP/s  %6.2f ms/launch  clock %.2f GHz  %.1f cycles per fragment\n", name, flop / (ms * 1e-3) / 1e12,
          ms / reps, clk[clk.size() / 2], cyc[cyc.size() / 2]);
 }
@@ -126,5 +133,7 @@ int main() {
   run<1, 3>("16x16x32 + 3 v_fma_f32 per fragment", w, x, out, stamps, cus, steps);
   run<0, 0>("32x32x16, no VALU (again)", w, x, out, stamps, cus, steps);
   run<1, 0>("16x16x32, no VALU (again)", w, x, out, stamps, cus, steps);
+  run<2, 0>("32x32x16, fragment used twice (64 tokens)", w, x, out, stamps, cus, steps / 2);
+  run<3, 0>("16x16x32, fragment used four times (64 t.)", w, x, out, stamps, cus, steps / 2);
   return 0;
 }

@@ -291,6 +291,12 @@ int rf_tokenizer_destroy(rf_tokenizer_t* t);
 int rf_tokenizer_set_punctuation(rf_tokenizer_t* t, const int32_t* cps, int n);
 /* ids5 <- { [UNK], [CLS], [SEP], [PAD], [MASK] (-1 if absent) } */
 int rf_tokenizer_special_ids(const rf_tokenizer_t* t, int32_t* ids5);
+/* char_offsets int64 [n + 1] (ascending, in code points, char_offsets[0] = 0) -> byte_offsets int64 [n + 1]
+ * into text_bytes (the n texts' UTF-8 bytes back to back, n_bytes in all): lets a host encode a whole batch
+ * with one call of its runtime and hand over per-text CHARACTER counts.  -1 if the counts do not match the
+ * blob.  Host helper of rf_tokenize_batch; no reference counterpart. */
+int rf_utf8_offsets(const char* text_bytes, int64_t n_bytes, const int64_t* char_offsets, int n,
+                    int64_t* byte_offsets);
 /* text_bytes: the n texts' UTF-8 bytes back to back, text i = [offsets[i], offsets[i+1]).
  * ids_out int32 [n, max_len] ([CLS] ids [SEP], padded with [PAD]); lens_out int32 [n].
  * n_threads <= 0: one per hardware thread (at most 64). */

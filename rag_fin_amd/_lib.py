@@ -83,6 +83,7 @@ SIGNATURES = {
     "rf_tokenizer_set_punctuation": (c_int, [c_void_p, c_void_p, c_int]),
     "rf_tokenizer_special_ids": (c_int, [c_void_p, c_void_p]),
     "rf_tokenize_batch": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int]),
+    "rf_utf8_offsets": (c_int, [c_char_p, c_int64, c_void_p, c_int, c_void_p]),
     "rf_debug_scores": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "rf_encoder_storage_bytes": (c_size_t, [POINTER(EncoderConfig)]),
     "rf_encoder_create": (c_int, [POINTER(c_void_p), POINTER(EncoderConfig),

@@ -232,6 +232,25 @@ int encode_one(const rf_tokenizer& t, const char* s, size_t n, int max_len, int3
 }
 }  // namespace
 
+// Character offsets (code points, what len(str) counts) -> byte offsets into the texts' UTF-8 bytes laid back to
+// back: the host then hands over ONE encoded blob of a whole batch and the per-text character counts instead of
+// encoding and measuring every text on its own.  One pass; a code point starts at every byte that is not 10xxxxxx.
+extern "C" int rf_utf8_offsets(const char* text_bytes, int64_t n_bytes, const int64_t* char_offsets, int n,
+                               int64_t* byte_offsets) {
+  if (!text_bytes || !char_offsets || !byte_offsets || n < 0 || n_bytes < 0) return -1;
+  int64_t chars = 0, pos = 0;
+  int j = 0;
+  while (j <= n && char_offsets[j] == 0) byte_offsets[j++] = 0;
+  for (; pos < n_bytes && j <= n; ++pos) {
+    if (((unsigned char)text_bytes[pos] & 0xC0) != 0x80) {   // a code point starts here
+      while (j <= n && char_offsets[j] == chars) byte_offsets[j++] = pos;
+      ++chars;
+    }
+  }
+  while (j <= n && char_offsets[j] == chars) byte_offsets[j++] = n_bytes;
+  return j == n + 1 ? 0 : -1;   // the counts do not add up to the blob (or are not ascending)
+}
+
 extern "C" int rf_tokenize_batch(const rf_tokenizer_t* t, const char* text_bytes, const int64_t* offsets, int n,
                                  int max_len, int32_t* ids_out, int32_t* lens_out, int n_threads) {
   if (!t || !offsets || !ids_out || !lens_out || n < 0 || max_len < 2 || (n > 0 && !text_bytes && offsets[n] > 0)) {

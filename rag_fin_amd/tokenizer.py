@@ -243,6 +243,23 @@ class WordPieceTokenizer:
             return s.translate(self._mn_punct_tab)   # strip Mn and pad punctuation in one pass
         return s.translate(self._punct_tab)
 
+    def _only_simple_non_ascii(self, joined: str) -> bool:
+        """True if every non-ASCII character of the batch is one the native rules handle as they are (no
+        pre-normalisation): decided on the batch's DISTINCT non-ASCII code units -- a handful -- instead of running
+        the character-class regex over megabytes of text (30 ms per 4 M characters; this: a UTF-16 view, one
+        comparison and one `unique` in numpy)."""
+        import numpy as np
+        try:
+            u16 = np.frombuffer(joined.encode("utf-16-le"), dtype=np.uint16)
+        except UnicodeEncodeError:                   # lone surrogates
+            return False
+        hi = np.unique(u16[u16 >= 128])
+        if hi.size == 0:
+            return True
+        if hi.size > 4096 or bool(((hi >= 0xD800) & (hi <= 0xDFFF)).any()):   # beyond the BMP: let the per-text path look
+            return False
+        return self._complex_re.search("".join(map(chr, hi.tolist()))) is None
+
     def batch_native(self, texts: list[str], max_length: int = 256, n_threads: int = 0):
         """Same result as batch(), through rf_tokenize_batch.  -> (ids int32 [B, T], lens int32 [B])."""
         import os
@@ -262,21 +279,40 @@ class WordPieceTokenizer:
         if n == 0:
             return np.full((0, 1), self.pad_id, dtype=np.int32), np.zeros((0,), dtype=np.int32)
         t_start = time.perf_counter()
-        enc, python_rows = [], {}
-        for i, t in enumerate(texts):
-            if not t.isascii() and self._complex_re.search(t) is not None:
-                t = self._prenormalise(t)
-                if t is None:
-                    python_rows[i] = self.encode(texts[i], max_length)
-                    t = ""
-            try:
-                enc.append(t.encode("utf-8"))
-            except UnicodeEncodeError:           # lone surrogates: Python path
-                python_rows[i] = self.encode(texts[i], max_length)
-                enc.append(b"")
+        python_rows = {}
         offsets = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum([len(b) for b in enc], out=offsets[1:])
-        blob = b"".join(enc)
+        joined = "".join(texts)
+        blob = None
+        if joined.isascii() or self._only_simple_non_ascii(joined):
+            # The usual ingest batch -- ASCII, or with "simple" non-ASCII characters only (a currency sign) that the
+            # native rules handle: ONE join, ONE test and ONE UTF-8 encode of the whole batch in C, the per-text
+            # character counts turned into byte offsets by rf_utf8_offsets -- instead of a Python loop that encoded and
+            # measured every text (1.6 us per text: most of the host's share of the text ingest).
+            try:
+                blob = joined.encode("utf-8")
+            except UnicodeEncodeError:               # a lone surrogate somewhere: the per-text path below sorts it out
+                blob = None
+        if blob is not None:
+            np.cumsum(np.fromiter(map(len, texts), dtype=np.int64, count=n), out=offsets[1:])
+            if len(blob) != int(offsets[n]):         # non-ASCII present: characters -> bytes
+                chars = offsets.copy()
+                _lib.check(lib.rf_utf8_offsets(blob, len(blob), c_void_p(chars.ctypes.data), n, c_void_p(offsets.ctypes.data)))
+        else:
+            enc = []
+            for i, t in enumerate(texts):
+                if not t.isascii() and self._complex_re.search(t) is not None:
+                    t = self._prenormalise(t)
+                    if t is None:
+                        python_rows[i] = self.encode(texts[i], max_length)
+                        t = ""
+                try:
+                    enc.append(t.encode("utf-8"))
+                except UnicodeEncodeError:           # lone surrogates: Python path
+                    python_rows[i] = self.encode(texts[i], max_length)
+                    enc.append(b"")
+            np.cumsum([len(b) for b in enc], out=offsets[1:])
+            blob = b"".join(enc)
+        del joined
         ids = np.empty((n, max_length), dtype=np.int32)
         lens = np.empty((n,), dtype=np.int32)
         t_native = time.perf_counter()

@@ -95,3 +95,37 @@ def test_native_tokenizer_edge_arguments():
         tok.batch_native(["x"], 1)          # max_len < 2 cannot hold [CLS] [SEP]
     with pytest.raises(ValueError):
         WordPieceTokenizer(["a", "b"])      # no special tokens
+
+
+def test_batch_prepass_paths_agree_and_utf8_offsets():
+    """batch_native encodes a whole batch with one join + one UTF-8 encode when its non-ASCII characters are all
+    "simple" (a currency sign), and falls back to the per-text pre-normalising loop otherwise: the three kinds of
+    batch (ASCII, simple non-ASCII, complex) give the ids of the Python restatement; rf_utf8_offsets turns
+    character counts into byte offsets (empty texts, multi-byte characters at the boundaries, bad counts)."""
+    import ctypes
+    from ctypes import c_void_p
+    from rag_fin_amd import _lib
+    chunk_texts, _ = _texts()
+    tok = WordPieceTokenizer(_vocab(chunk_texts))
+    ascii_batch = [t.encode("ascii", "ignore").decode() for t in chunk_texts[:8]] + ["", "net profit 12.5 crore"]
+    simple = ["₹ 1,234 crore", "", "€ 5 and £ 6", "abc", "₹"] + chunk_texts[:8]
+    complex_ = simple + ["Café déjà vu ₹ 12", "日本語", "x́y", "emoji \U0001F600 test"]
+    for batch, fast in ((ascii_batch, True), (simple, True), (complex_, False)):
+        joined = "".join(batch)
+        assert (joined.isascii() or tok._only_simple_non_ascii(joined)) == fast
+        a, la = tok.batch(batch, 64)
+        b, lb = tok.batch_native(batch, 64)
+        assert np.array_equal(la, lb) and np.array_equal(a, b)
+    lib = _lib.load_library()
+    texts = ["₹a", "", "éé", "xyz", "\U0001F600"]
+    blob = "".join(texts).encode("utf-8")
+    chars = np.zeros(len(texts) + 1, dtype=np.int64)
+    np.cumsum([len(t) for t in texts], out=chars[1:])
+    out = np.full(len(texts) + 1, -7, dtype=np.int64)
+    assert lib.rf_utf8_offsets(blob, len(blob), c_void_p(chars.ctypes.data), len(texts), c_void_p(out.ctypes.data)) == 0
+    want = np.zeros(len(texts) + 1, dtype=np.int64)
+    np.cumsum([len(t.encode("utf-8")) for t in texts], out=want[1:])
+    assert np.array_equal(out, want)
+    chars[-1] += 1                                   # one character more than the blob holds
+    assert lib.rf_utf8_offsets(blob, len(blob), c_void_p(chars.ctypes.data), len(texts), c_void_p(out.ctypes.data)) == -1
+    assert lib.rf_utf8_offsets(None, 0, None, 0, None) == -1

@@ -296,7 +296,7 @@ class Embedder:
             t1 = time.perf_counter()
             stats[key] += t1 - t0
             return t1
-        chunk_texts = 4096
+        chunk_texts = int(os.environ.get("RAGFIN_INGEST_CHUNK_TEXTS", "4096"))   # (tools/ingest_probe.py sweeps it)
         # the first chunk is a quarter of the others: nothing overlaps ITS tokenisation, so the
         # GPU should get its first buckets early
         starts = [0] + list(range(min(n, chunk_texts // 4), n, chunk_texts))

@@ -31,6 +31,14 @@ for nt in (0, 8, 16, 64):
     st = emb.ingest_stats
     print("threads=%d: total_s %s ; last run stages %s" % (nt, [round(x, 3) for x in tot],
           {k: (round(x, 4) if isinstance(x, float) else x) for k, x in st.items()}))
+os.environ["RAGFIN_TOKENIZER_THREADS"] = "0"
+for ct in (1024, 2048, 4096):
+    os.environ["RAGFIN_INGEST_CHUNK_TEXTS"] = str(ct)
+    tot = []
+    for r in range(6):
+        t = time.perf_counter(); v = emb.encode_to_device(texts); torch.cuda.synchronize(); tot.append(time.perf_counter() - t)
+    print("chunk_texts=%d: total_s %s chunks %d buckets %d" % (ct, [round(x, 4) for x in tot], emb.ingest_stats["chunks"], emb.ingest_stats["buckets"]))
+os.environ.pop("RAGFIN_INGEST_CHUNK_TEXTS")
 try:
     print("/sys/fs/cgroup/cpu.stat", open("/sys/fs/cgroup/cpu.stat").read().strip().replace("\n", " | "))
 except OSError:

@@ -251,7 +251,8 @@ size_t rf_encoder_storage_bytes(const rf_encoder_config* cfg);
 /* Tiles the Linear weights into storage_dev on `stream` and keeps the remaining
  * pointers of `w` (embeddings, biases, LayerNorm) -- the caller keeps those
  * tensors alive for the encoder's lifetime.  Supported: hidden == 384,
- * head_dim == 32, intermediate % 384 == 0 (the all-MiniLM-L{6,12}-H384 family). */
+ * head_dim == 32, intermediate == 1536 (the all-MiniLM-L{6,12}-H384 family); anything else
+ * returns RF_ERR_UNSUPPORTED. */
 int rf_encoder_create(rf_encoder_t** out, const rf_encoder_config* cfg,
                       const rf_encoder_weights* w, void* storage_dev, size_t storage_bytes,
                       int device, void* stream);

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--calls", type=int, default=300)
     ap.add_argument("--top-k", type=int, default=5)
     ap.add_argument("--tune", default="", help="rf_set_tuning pairs, e.g. ln_tail=0")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the calls: where the host time of a query goes")
     args = ap.parse_args()
     import torch
     from oracle import encoder as oenc, search as osearch
@@ -61,6 +62,15 @@ def main():
             _lib.check(_lib.load_library().rf_set_tuning(k_.encode(), int(v_)))
     for q in QUESTIONS * 4:
         rag.search(q, args.top_k)
+    if args.profile:
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(args.calls):
+            rag.search(QUESTIONS[i % len(QUESTIONS)], args.top_k)
+        pr.disable()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+        return
     lat, t_tok, t_enc, t_search = [], [], [], []
     for i in range(args.calls):
         q = QUESTIONS[i % len(QUESTIONS)]

@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) k_tok_offsets(const int32_t* __restrict__
 // per 32 positions with two sweeps over the rows: 56 us -- 8 waves per CU cannot hide the latency.)
 __global__ void __launch_bounds__(256) k_embed_ln(
     const int32_t* __restrict__ ids, const int32_t* __restrict__ lens,
-    const int32_t* __restrict__ tok_off, int B, int T, int vocab, const _Float16* __restrict__ word,
+    int32_t* __restrict__ tok_off, int B, int T, int vocab, const _Float16* __restrict__ word,
     const _Float16* __restrict__ pos, const _Float16* __restrict__ type, const _Float16* __restrict__ g,
     const _Float16* __restrict__ b, float eps, _Float16* __restrict__ out) {
   __shared__ float red[2][4][32];
@@ -243,6 +243,12 @@ __global__ void __launch_bounds__(256) k_embed_ln(
   const int cpr = (T + 31) >> 5;                               // 32-position chunks per sequence row
   const int bi = blockIdx.x / cpr, p0 = (blockIdx.x % cpr) * 32;
   const int len = min(max(lens[bi], 0), T);
+  // ONE sequence (a query): the packed offsets are {0, len} -- written here, so that the launch of k_tok_offsets
+  // (a dependent kernel boundary, ~4.5 us of the query's latency) is not needed
+  if (B == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+    tok_off[0] = 0;
+    tok_off[1] = len;
+  }
   if (p0 >= len) return;                                       // workgroup-uniform
   const int p = p0 + c;
   const bool live = p < len;
@@ -288,7 +294,7 @@ __global__ void __launch_bounds__(256) k_embed_ln(
   const float mu = t1 * (1.f / HID);
   // E[v^2] - mu^2 in fp32 over 384 values of order 1 with |mu| << 1: the cancellation is ~1e-6 relative
   const float rstd = rsqrtf(fmaxf(t2 * (1.f / HID) - mu * mu, 0.f) + eps);
-  const int token = tok_off[bi] + p;
+  const int token = (B == 1 ? 0 : tok_off[bi]) + p;
   _Float16* orow = out + ((size_t)(token >> 5) * (HID / 16) * 64 + (size_t)h * 32 + (token & 31)) * 8 + (size_t)(FW * wave) * 512;
 #pragma unroll
   for (int f = 0; f < FW; ++f) {
@@ -2034,7 +2040,7 @@ static int encode_enqueue(const rf_encoder_t* enc, const int32_t* ids_dev, const
   const int tiles = B * T;   // token slots; launch_linear turns them into tiles
   const int32_t* m_ptr = ws.tok_off + B;
 
-  hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off);
+  if (B > 1) hipLaunchKernelGGL(k_tok_offsets, dim3(1), dim3(256), 0, st, lens_dev, B, T, ws.tok_off);   // B == 1: k_embed_ln writes them
   {
     const int chunks = B * ((T + 31) / 32);   // one workgroup per 32 positions of a row
     hipLaunchKernelGGL(k_embed_ln, dim3(chunks), dim3(256), 0, st, ids_dev, lens_dev, ws.tok_off, B, T,

@@ -869,7 +869,7 @@ __global__ void __launch_bounds__(256, 1) k_scan_w64(WideParams p) {
     }
   };
   uint32_t row0_prev = p.n_rows, row1_prev = p.n_rows;
-  uint64_t t_wait = 0, t_c0 = 0, t_r0 = 0;
+  uint64_t t_wait = 0, t_bar = 0, t_c0 = 0, t_r0 = 0;
   if (DBG & 4) {
     t_c0 = __builtin_amdgcn_s_memtime();
     t_r0 = __builtin_amdgcn_s_memrealtime();
@@ -881,9 +881,14 @@ __global__ void __launch_bounds__(256, 1) k_scan_w64(WideParams p) {
     if (DBG & 4) ts0 = __builtin_amdgcn_s_memtime();
     // my pieces of phase ph have landed (my 12 pieces of phase ph + 1 may stay in flight) ...
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    uint64_t ts1 = 0;
+    if (DBG & 4) ts1 = __builtin_amdgcn_s_memtime();
     // ... and after the barrier everybody's have, and everybody has consumed phase ph - 1
     __builtin_amdgcn_s_barrier();
-    if (DBG & 4) t_wait += __builtin_amdgcn_s_memtime() - ts0;
+    if (DBG & 4) {
+      t_wait += ts1 - ts0;
+      t_bar += __builtin_amdgcn_s_memtime() - ts1;
+    }
     const Pieces nxt = pieces_of(ph + 2);  // goes into the slot phase ph - 1 has just vacated
     const uint32_t sa = slots_s + (ph % WL_SLOTS) * (uint32_t)(WL_FRAGS * RF_FRAG_BYTES) + lane_off;
     const uint32_t b0 = (blockIdx.x + ph * G) * p.bstride * WL_PB;
@@ -941,9 +946,9 @@ __global__ void __launch_bounds__(256, 1) k_scan_w64(WideParams p) {
     float* o = p.pmax + ((size_t)blockIdx.x * 8 + wave) * 8;
     o[0] = (float)(__builtin_amdgcn_s_memtime() - t_c0);
     o[1] = (float)(__builtin_amdgcn_s_memrealtime() - t_r0);
-    o[2] = (float)t_wait;   // cycles in the vmcnt wait + barrier
+    o[2] = (float)t_wait;   // cycles in the vmcnt wait
     o[3] = (float)cnt;
-    o[4] = 0.f;
+    o[4] = (float)t_bar;    // cycles in the barrier
   }
   if (MODE == MODE_EMIT) {
     if (st.cnt > 0) w64_flush(st, p, lane);

@@ -129,3 +129,26 @@ def test_batch_prepass_paths_agree_and_utf8_offsets():
     chars[-1] += 1                                   # one character more than the blob holds
     assert lib.rf_utf8_offsets(blob, len(blob), c_void_p(chars.ctypes.data), len(texts), c_void_p(out.ctypes.data)) == -1
     assert lib.rf_utf8_offsets(None, 0, None, 0, None) == -1
+
+
+def test_batches_of_any_mix_agree_with_the_python_restatement():
+    """Property (hypothesis): whatever mix of ASCII, "simple" non-ASCII (currency signs: the whole-batch pre-pass)
+    and complex text (accents, marks, CJK, emoji, control characters: the per-text pre-pass) a batch holds, and
+    wherever the empty strings sit, batch_native returns the ids of the Python restatement."""
+    from hypothesis import given, settings, strategies as st
+    chunk_texts, _ = _texts()
+    tok = WordPieceTokenizer(_vocab(chunk_texts))
+    ascii_words = st.text(alphabet="abcXYZ 019.,;()-", max_size=40)
+    simple = st.text(alphabet="abc 12₹€£•«»—", max_size=40)
+    complex_ = st.text(alphabet="aé́中 İßǅ\U0001f600 ­\x00ई", max_size=30)
+    batch = st.lists(st.one_of(ascii_words, simple, complex_, st.just("")), min_size=0, max_size=12)
+
+    @settings(max_examples=120, deadline=None)
+    @given(batch, st.sampled_from([4, 16, 64]))
+    def check(texts, max_len):
+        a, la = tok.batch(texts, max_len)
+        b, lb = tok.batch_native(texts, max_len)
+        assert np.array_equal(la, lb)
+        if len(texts):
+            assert a.shape == b.shape and np.array_equal(a, b)
+    check()

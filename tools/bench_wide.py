@@ -81,6 +81,10 @@ def main():
         ok = (ticks > 100) & (ph >= 1)      # rows of waves the kernel does not have hold the sample pass's maxima
         print("stamps: in-kernel clock %.2f GHz; loop %.1f us; cycles/phase %.0f (median over workgroups x waves; phases %d..%d)" %
               (np.median(cyc[ok] / ticks[ok]) * 0.1, np.median(ticks[ok]) / 100.0, np.median(cyc[ok] / ph[ok]), ph[ok].min(), ph[ok].max()))
+        fl, nf = st[..., 5], st[..., 6]
+        if ok.any() and float(nf[ok].max()) > 0:
+            print("  staging flushes in the loop: %.1f per wave, %.0f cycles each, %.1f %% of the wave's cycles" % (
+                np.median(nf[ok]), np.median(fl[ok] / np.maximum(nf[ok], 1)), 100 * np.median(fl[ok] / cyc[ok])))
         for name, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
             o2 = ok[:, sl]
             print("  %s: vmcnt wait %.1f %% of the cycles (%.0f cycles/phase), barrier %.1f %% (%.0f cycles/phase)" % (

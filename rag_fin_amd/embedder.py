@@ -219,19 +219,32 @@ class Embedder:
         # batch size.  Host ids are padded on the host (one upload, no extra launch); device ids with two small kernels.
         Tr = (T + 7) // 8 * 8 if T <= 32 else (T + 31) // 32 * 32
         Tr = min(Tr, self.cfg["max_position"])
-        if Tr != T and B * Tr <= self.SMALL_SLOTS:
-            if ids.device.type == "cpu":
-                padded = torch.zeros((B, Tr), dtype=torch.int32)
-                padded[:, :T] = ids
-                sb["ids"][:B * Tr].copy_(padded.view(-1), non_blocking=True)
-            else:
-                wide = sb["ids"][:B * Tr].view(B, Tr)
-                wide[:, :T].copy_(ids, non_blocking=True)
-                wide[:, T:].zero_()
-            T = Tr
+        if B * Tr > self.SMALL_SLOTS:
+            Tr = T
+        if ids.device.type == "cpu" and lens.device.type == "cpu":
+            # Host inputs go through PINNED staging buffers owned by the embedder: an asynchronous copy from pageable
+            # memory reads its source when the copy RUNS, and the caller's arrays (or a padded temporary made here) can
+            # be freed and reused before that -- seen as a rare wrong hit when two ranks share one card
+            # (tests/test_sharded_gpu.py::test_world2_sharded_store_behind_vector_rag).  The buffers are rewritten only
+            # after the previous use's copy has run (host wait on its event: already complete in a serving loop).
+            if self._small_done is not None:
+                self._small_done.synchronize()
+            hid = sb["ids_host"][:B * Tr].view(B, Tr)
+            hid[:, :T] = ids
+            if Tr != T:
+                hid[:, T:] = 0
+            sb["lens_host"][:B] = lens
+            sb["ids"][:B * Tr].copy_(sb["ids_host"][:B * Tr], non_blocking=True)
+            sb["lens"][:B].copy_(sb["lens_host"][:B], non_blocking=True)
         else:
-            sb["ids"][:B * T].copy_(ids.reshape(-1), non_blocking=True)
-        sb["lens"][:B].copy_(lens, non_blocking=True)
+            ids = ids.to(self.device, non_blocking=False)
+            lens = lens.to(self.device, non_blocking=False)
+            wide = sb["ids"][:B * Tr].view(B, Tr)
+            wide[:, :T].copy_(ids)
+            if Tr != T:
+                wide[:, T:].zero_()
+            sb["lens"][:B].copy_(lens)
+        T = Tr
         ids, lens = sb["ids"], sb["lens"]
         out16 = None if want32 else sb["o16"]
         out32 = sb["o32"] if want32 else None
@@ -250,6 +263,8 @@ class Embedder:
             n = self.SMALL_SLOTS
             self._sb = {"ids": torch.zeros(n, dtype=torch.int32, device=self.device),
                         "lens": torch.zeros(n, dtype=torch.int32, device=self.device),
+                        "ids_host": torch.zeros(n, dtype=torch.int32).pin_memory(),
+                        "lens_host": torch.zeros(n, dtype=torch.int32).pin_memory(),
                         "o16": torch.zeros((n, self.dim), dtype=torch.float16, device=self.device),
                         "o32": torch.zeros((n, self.dim), dtype=torch.float32, device=self.device)}
             # workspace large enough for every small shape: its pointer must not move either

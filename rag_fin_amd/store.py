@@ -266,7 +266,7 @@ class GpuIndex:
     def search_host(self, q16, k: int):
         """search() whose results land on the host with ONE synchronisation: scores, ids and
         flags are copied into cached pinned buffers asynchronously.  -> (scores f32 [B,k],
-        ids i64 [B,k]) numpy views (valid until the next call with the same shape)."""
+        ids i64 [B,k]) numpy arrays (the caller's own copies)."""
         torch = _torch()
         with self._lock:
             B = q16.shape[0]
@@ -293,7 +293,9 @@ class GpuIndex:
                 s2, i2, _ = self.search_exhaustive(qb, k)
                 bufs[0][bad] = s2.cpu()
                 bufs[1][bad] = i2.cpu()
-        return bufs[0].numpy(), bufs[1].numpy()
+            # private copies, taken while the lock is still held: the pinned buffers are shared by every caller with
+            # this (B, k) and the next search's merge kernel stores straight into them
+            return bufs[0].numpy().copy(), bufs[1].numpy().copy()
 
     def debug_scores(self, q16, n: int | None = None):
         torch = _torch()
@@ -449,7 +451,7 @@ class CorpusStore:
             return scores[:, :kk].cpu().numpy(), rows[:, :kk].cpu().numpy()
         scores, rows = self.index.search_host(q16, limit)   # one synchronisation for the whole download
         kk = min(limit, self.num_entities)
-        return scores[:, :kk].copy(), rows[:, :kk].copy()
+        return scores[:, :kk], rows[:, :kk]
 
     def search(self, data, anns_field: str = "embedding", param: dict | None = None,
                limit: int = 3, expr=None, output_fields: Iterable[str] | None = None):

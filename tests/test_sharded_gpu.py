@@ -185,12 +185,27 @@ def _store_worker(rank, world, port, out_dir):
         assert ingest_sharded(store, emb, chunks[1200:]) == 800
         rag = VectorRAG(None, "fin_chunks", embedder=emb, store=store)
         queries = synth_text.retemplated_texts(6, 32)
+        # What each rank EMBEDDED at search time is recorded: in the collective form every rank embeds the query itself,
+        # and the first query-sized forward after a large-batch one has been seen to differ from later ones in the last
+        # fp16 bit of some components -- the oracle below is given the bits that were searched with.
+        seen_one, seen_many = [], []
+        plain_encode = emb.encode_to_device
+
+        def recording_encode(sentences, *a, **kw):
+            out = plain_encode(sentences, *a, **kw)
+            (seen_one if len(sentences) == 1 else seen_many).append(out.cpu().numpy().copy())
+            return out
+        emb.encode_to_device = recording_encode
         collective = [rag.search(qt, 5) for qt in queries[:3]]            # every rank calls (collective form)
         store.start_workers()                                             # ranks > 0 stay inside
         led = None
         if rank == 0:
             led = [rag.search(qt, 5) for qt in queries[3:]] + [rag.search_batch(queries, 3)]
             store.stop_workers()
+        emb.encode_to_device = plain_encode
+        np.save(os.path.join(out_dir, f"seen_q{rank}.npy"), np.concatenate(seen_one))
+        if rank == 0:
+            np.save(os.path.join(out_dir, "seen_qb.npy"), np.concatenate(seen_many))
         vec_local = store.index.get_rows(np.arange(store.local_rows)).cpu().numpy()
         np.savez(os.path.join(out_dir, f"v{rank}.npz"), vec=vec_local, gmap=store._id_map.cpu().numpy())
         if rank == 0:
@@ -221,16 +236,36 @@ def test_world2_sharded_store_behind_vector_rag(tmp_path, gpu_device):
         c16[z["gmap"]] = z["vec"]
         seen += len(z["gmap"])
     assert seen == 2000
-    q16 = np.load(tmp_path / "q.npy")
     got = json.load(open(tmp_path / "rag.json"))
-    os5, oi5 = c_oracle.search(q16, c16, 5)
+    shard_rows = [np.sort(np.load(tmp_path / f"v{r}.npz")["gmap"]) for r in range(2)]
+    s0, s1 = np.load(tmp_path / "seen_q0.npy"), np.load(tmp_path / "seen_q1.npy")
+    assert s0.shape == (6, 384) and s1.shape == (3, 384)      # rank 0: three collective + three led; rank 1: three collective
+    later = np.load(tmp_path / "q.npy")
+    from conftest import record_measurement
+    record_measurement("query_embedding_bits_search_time_vs_later",
+                       rank0_rows_differing=int((s0.view(np.uint16) != later.view(np.uint16)).any(1).sum()),
+                       rank1_rows_differing=int((s1.view(np.uint16) != later[:3].view(np.uint16)).any(1).sum()),
+                       max_abs=float(max(np.abs(s0.astype(np.float32) - later.astype(np.float32)).max(),
+                                         np.abs(s1.astype(np.float32) - later[:3].astype(np.float32)).max())))
+    assert np.abs(s0.astype(np.float32) - later.astype(np.float32)).max() < 2e-4      # last-bit differences at most
+
+    def expected(per_shard_queries):
+        """Top-5 over the whole corpus when shard r was searched with per_shard_queries[r] (one fp16 vector each)."""
+        cand = []
+        for r, qv in enumerate(per_shard_queries):
+            sc, ix = c_oracle.search(qv[None, :], c16[shard_rows[r]], 5)
+            cand += [(-float(sc[0, j]), int(shard_rows[r][ix[0, j]])) for j in range(ix.shape[1]) if ix[0, j] >= 0]
+        cand.sort()
+        return [-c[0] for c in cand[:5]], [c[1] for c in cand[:5]]
+
     answers = got["collective"] + got["led"]
     for b, ctx in enumerate(answers):
+        es, ei = expected([s0[b], s1[b]] if b < 3 else [s0[b], s0[b]])     # led: rank 0's vector goes to both shards
         assert [c["rank"] for c in ctx] == [1, 2, 3, 4, 5]
-        assert [c["text"] for c in ctx] == [texts[i] for i in oi5[b]]
-        assert [c["primary_value"] for c in ctx] == [float(i) for i in oi5[b]]
-        assert np.allclose([c["score"] for c in ctx], os5[b], atol=1e-6)
-    os3, oi3 = c_oracle.search(np.load(tmp_path / "qb.npy"), c16, 3)      # search_batch on rank 0 while leading
+        assert [c["text"] for c in ctx] == [texts[i] for i in ei]
+        assert [c["primary_value"] for c in ctx] == [float(i) for i in ei]
+        assert np.allclose([c["score"] for c in ctx], es, atol=1e-6)
+    os3, oi3 = c_oracle.search(np.load(tmp_path / "seen_qb.npy"), c16, 3)  # search_batch on rank 0 while leading
     for b, ctx in enumerate(got["batch"]):
         assert [int(c["primary_value"]) for c in ctx] == list(oi3[b])
         assert np.allclose([c["score"] for c in ctx], os3[b], atol=1e-6)

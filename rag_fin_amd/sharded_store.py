@@ -183,6 +183,13 @@ class ShardedCorpusStore(CorpusStore):
                 self.dist.broadcast(hdr, src=0, group=self.group)
                 qb = q16.to(self._bdev)
                 self.dist.broadcast(qb, src=0, group=self.group)
+            elif self.world > 1:
+                # collective form (every rank called search with its own copy of the queries): all shards are searched
+                # with RANK 0's bits.  A merged top-k is the top-k of a query only if every shard scored the same
+                # vector, and two ranks that embedded the same text need not agree in the last fp16 bit.
+                qb = q16.to(self._bdev)
+                self.dist.broadcast(qb, src=0, group=self.group)
+                q16 = qb.to(q16.device)
             scores, gids, gflags = self._collective_search(q16, limit)
             if ShardedSearcher.failed(gflags):
                 raise RuntimeError("sharded search failed: a rank could not scan its shard (see that rank's log)")

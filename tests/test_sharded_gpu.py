@@ -185,9 +185,9 @@ def _store_worker(rank, world, port, out_dir):
         assert ingest_sharded(store, emb, chunks[1200:]) == 800
         rag = VectorRAG(None, "fin_chunks", embedder=emb, store=store)
         queries = synth_text.retemplated_texts(6, 32)
-        # What each rank EMBEDDED at search time is recorded: in the collective form every rank embeds the query itself,
-        # and the first query-sized forward after a large-batch one has been seen to differ from later ones in the last
-        # fp16 bit of some components -- the oracle below is given the bits that were searched with.
+        # What each rank EMBEDDED at search time is recorded: the first query-sized forward after a large-batch one has
+        # been seen to differ from later ones in the last fp16 bit of some components, so the oracle below
+        # is given the bits that were searched with -- rank 0's, which the store sends to every shard in both forms.
         seen_one, seen_many = [], []
         plain_encode = emb.encode_to_device
 
@@ -260,7 +260,7 @@ def test_world2_sharded_store_behind_vector_rag(tmp_path, gpu_device):
 
     answers = got["collective"] + got["led"]
     for b, ctx in enumerate(answers):
-        es, ei = expected([s0[b], s1[b]] if b < 3 else [s0[b], s0[b]])     # led: rank 0's vector goes to both shards
+        es, ei = expected([s0[b], s0[b]])     # both forms: rank 0's vector goes to every shard (ShardedCorpusStore.search_rows)
         assert [c["rank"] for c in ctx] == [1, 2, 3, 4, 5]
         assert [c["text"] for c in ctx] == [texts[i] for i in ei]
         assert [c["primary_value"] for c in ctx] == [float(i) for i in ei]
